@@ -1,0 +1,147 @@
+/*
+ * par_raytracer.h — C ABI of the MI355X-native pixel-art raytracer (libpar_raytracer.so).
+ *
+ * This is the drop-in boundary for the reference's render call: the three statements plus the inline loop in
+ * `main` at src/alternative.cpp:690-760 (memset + count_entities_in_bins + trace_hash_for_pixel + the
+ * shading/quantise loop around trace_hash_for_light). The reference has no FFI of its own; each entry
+ * point below names the reference interface it replaces (alt = src/alternative.cpp, spr = src/sprites.hpp).
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no exceptions cross this boundary; every call returns a par_status.
+ *   - ownership follows the reference (alt:503-517): the caller owns every input and output buffer; the context
+ *     owns only its device-side copies and work arrays.
+ *   - one context = one GPU = one host thread at a time (the reference is single-threaded).
+ *   - the library REQUIRES a gfx950 device: there is no CPU fallback. par_create fails with PAR_ERR_NO_DEVICE.
+ */
+#ifndef PAR_RAYTRACER_H
+#define PAR_RAYTRACER_H
+
+#include "par_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct par_context par_context;
+
+typedef enum par_status {
+    PAR_OK = 0,
+    PAR_ERR_INVALID_ARG = 1, /* null pointer, negative size, rows out of range, ambient outside [0,1] ... */
+    PAR_ERR_NO_DEVICE = 2,   /* no HIP device / not gfx950 */
+    PAR_ERR_HIP = 3,         /* a HIP runtime call failed; see par_last_error */
+    PAR_ERR_OOM = 4,         /* host or device allocation failed */
+    PAR_ERR_UNSUPPORTED = 5, /* grid dimension or bin size outside what the kernels are built for */
+    PAR_ERR_EXTENT = 6,      /* an AABB extent the 20x40 sprite cannot express (reference UB: alt:330, SURVEY a-3b) */
+    PAR_ERR_SPRITE_ID = 7,   /* sprite id or sprite palette index out of range */
+    PAR_ERR_NOT_READY = 8    /* render before sprites / entities / light were set */
+} par_status;
+
+/* Render flags. */
+enum {
+    /* Cast the shadow ray of uncovered (background) pixels too, as the reference does (alt:703,738). Their colour
+     * cannot depend on the result (SURVEY a-6), so by default the ray is skipped; requesting the `lit` plane turns
+     * this on implicitly because the result then is observable. */
+    PAR_RENDER_TRACE_BACKGROUND = 1u << 0,
+    /* Count the shadow rays actually traced into par_frame_stats (one atomic per workgroup). */
+    PAR_RENDER_COUNT_RAYS = 1u << 1
+};
+
+/* Output planes of one render, each nullable. Every pointer addresses the element of (row_begin, column 0);
+ * a plane holds (row_end - row_begin) * width elements, row-major like the reference's buffers. */
+typedef struct par_outputs {
+    par_color* fb;     /* final RGBA8 frame, `p_texture` alt:515,735,757 */
+    par_pixel* gbuf;   /* G-buffer, `p_pixel_buffer` alt:511,379 */
+    uint8_t* palidx;   /* sprite palette index per pixel (alt:352-354), PAR_PALIDX_BACKGROUND where uncovered */
+    float* brightness; /* pre-quantise brightness factor: ambient or min(1, diffuse + ambient), alt:735,757-758 */
+    uint8_t* lit;      /* 1 where trace_hash_for_light returned true (alt:738) */
+} par_outputs;
+
+typedef struct par_frame_stats {
+    int64_t entities;        /* entities uploaded */
+    int64_t bin_insertions;  /* (entity, bin) pairs inserted this frame (alt:243-267 iterations) */
+    int64_t shadow_rays;     /* shadow rays traced (only with PAR_RENDER_COUNT_RAYS), else -1 */
+    float ms_bin;            /* device time of the binning kernels of the last timed render, else -1 */
+    float ms_render;         /* device time of the render kernel of the last timed render, else -1 */
+} par_frame_stats;
+
+const char* par_status_string(int status);
+/* Detail of the last failure on this context ("" when none). The pointer stays valid until the next call. */
+const char* par_last_error(const par_context* ctx);
+
+/* Reference defaults: 480x320x320, bin 40, ambient 0.25, background 127, 4-entry gray palette
+ * (alt:116-131, alt:281, alt:702, spr:60-65). */
+void par_default_params(par_params* params);
+/* hash_width/height/length (alt:120-122) for these parameters. */
+int par_grid_dims(const par_params* params, int* gx, int* gy, int* gz);
+
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int par_device_count(void);
+
+/* Create a renderer on HIP device `device` (-1: the current device). Allocates the grid and work arrays. */
+int par_create(const par_params* params, int device, par_context** out);
+void par_destroy(par_context* ctx);
+
+/* --- scene surface: replaces `Entities<N>{aabbs, sprites}` (alt:92-114) and `lights` (alt:619-626) ----------- */
+
+/* Unique sprite table. Palette indices are validated against params.palette_size. */
+int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites);
+/* All entities; entity index == array index (alt:93-97). `sprite_ids` nullable (all entities use sprite 0). */
+int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* sprite_ids, int n);
+/* The reference's own layout: one Sprite per entity (`std::vector<Sprite>`, alt:95,107). Identical sprites are
+ * stored once on the device; entity order is kept. */
+int par_set_entities_ref_layout(par_context* ctx, const par_aabb* aabbs, const par_sprite* sprite_per_entity, int n);
+/* Per-frame mutation (alt:643-660 moves aabbs[0]): overwrite aabbs[first, first+n). */
+int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n);
+/* lights[0] (alt:712-714, 729-732: the only light the reference reads). */
+int par_set_light(par_context* ctx, const par_light* light);
+
+/* --- render: replaces alt:690-760 ----------------------------------------------------------------------------- */
+
+/* One frame into caller-owned HOST buffers: bin, trace, shade, copy back, synchronise. */
+int par_render(par_context* ctx, const par_outputs* host_out, unsigned flags);
+/* Rows [row_begin,row_end) only (multi-GPU row-block sharding); host buffers, synchronous. */
+int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outputs* host_out, unsigned flags);
+/* Asynchronous: enqueue on `stream` (a hipStream_t, NULL = default stream) writing DEVICE buffers. No sync. */
+int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
+                      unsigned flags);
+/* As par_render_device, bracketing the binning and render kernels with HIP events on `stream`; blocks until the
+ * frame is done and fills stats->ms_bin / ms_render. */
+int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int row_end,
+                            const par_outputs* device_out, unsigned flags, par_frame_stats* stats);
+
+/* hipGraph path (BASELINE config 5): capture {pinned-host AABB/light upload -> bin -> render} once, replay per
+ * frame. `par_graph_stage` writes the next frame's AABBs/light into the pinned staging area the graph copies from. */
+int par_graph_capture(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
+                      unsigned flags);
+int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, const par_light* light);
+int par_graph_launch(par_context* ctx, void* stream);
+
+/* Mouse pick (alt:380-382, 698-700): the G-buffer texel under (x, y) of the last frame rendered with a gbuf
+ * plane is the caller's to read; this helper renders just that pixel's row. */
+int par_pick(par_context* ctx, int x, int y, par_pixel* out);
+
+/* Statistics of the last render (blocks until it finished). */
+int par_get_stats(par_context* ctx, par_frame_stats* stats);
+
+/* Read back the spatial hash of the last render in the reference's layout (`count[G]`, `map[G*8]`,
+ * `bins[G*8]`, alt:503-509). Only slots below count[b] are defined; the others are zero. Parity tooling. */
+int par_read_grid(par_context* ctx, int32_t* count, int32_t* map, par_aabb* bins);
+
+/* --- host-side scene helpers (C++ host code, no GPU needed) ---------------------------------------------------- */
+
+/* `make_tile_floor` (spr:73-364). */
+void par_sprite_tile_floor(par_sprite* out);
+/* The graybox world of alt:517-599 for a view of width x length (480 x 320 in the reference). Returns the entity
+ * count (162 308 for the reference view); writes at most `capacity` AABBs. */
+int par_scene_graybox(int view_width, int view_length, par_aabb* out, int capacity);
+/* Synthetic benchmark scene: n boxes of extent (20,20,20), positions from splitmix64(seed):
+ * x in [-20,width), y in [-20,200), z in [-20,length). Also returns the light (5w/8, h/2, l/4). */
+int par_scene_synthetic(int n, int width, int height, int length, uint64_t seed, par_aabb* out, par_light* light);
+/* Debug overlay of alt:763-772 (Bresenham line from the picked pixel to the light) drawn into a host frame. */
+void par_debug_line(const par_params* params, const par_pixel* pick, int mouse_x, const par_light* light,
+                    par_color* fb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAR_RAYTRACER_H */

@@ -1,0 +1,233 @@
+"""ctypes loader for the test-only checker libraries. TEST INFRASTRUCTURE: the product never imports this.
+
+  Oracle      oracle/libpar_oracle.so    — our parameterised CPU restatement (travels to the GPU box prebuilt)
+  Reference   oracle/_ref/libref_path.so — the reference's own functions (build container only; 480x320x320)
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+T = importlib.import_module("pixel-art-raytracer_amd.types")
+
+
+class Grid(C.Structure):
+    _fields_ = [("gx", C.c_int), ("gy", C.c_int), ("gz", C.c_int), ("volume", C.c_int), ("count", C.c_void_p),
+                ("map", C.c_void_p), ("bins", C.c_void_p)]
+
+
+class _V3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class GridArrays:
+    """count / map / bins arrays in the reference layout (alt:503-509), zero-initialised."""
+
+    def __init__(self, params):
+        self.gx, self.gy, self.gz = params.grid_dims()
+        self.volume = self.gx * self.gy * self.gz
+        self.count = np.zeros(self.volume, dtype=np.int32)
+        self.map = np.zeros(self.volume * T.SLOTS, dtype=np.int32)
+        self.bins = np.zeros(self.volume * T.SLOTS, dtype=T.AABB)
+
+    def c(self):
+        return Grid(self.gx, self.gy, self.gz, self.volume, T.ptr(self.count), T.ptr(self.map), T.ptr(self.bins))
+
+    def dump(self):
+        return self.count.tobytes() + self.map.tobytes() + self.bins.tobytes()
+
+    def visible(self):
+        """The defined part of the hash: per bin, count and the (entity, aabb bytes) of slots below count."""
+        live = np.nonzero(self.count)[0]
+        out = {}
+        for b in live:
+            c = int(self.count[b])
+            out[int(b)] = [(int(self.map[b * T.SLOTS + s]), self.bins[b * T.SLOTS + s].tobytes()[:12])
+                           for s in range(c)]
+        return out
+
+
+class Oracle:
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "libpar_oracle.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path}: build it with `make -C oracle` (or __graft_entry__.build())")
+        self.lib = L = C.CDLL(path)
+        L.par_oracle_color_scale.restype = T.Color
+        L.par_oracle_color_scale.argtypes = [T.Color, C.c_float]
+        L.par_oracle_normalize.restype = _V3
+        L.par_oracle_normalize.argtypes = [_V3]
+        L.par_oracle_intersect.restype = C.c_int
+        L.par_oracle_intersect.argtypes = [C.c_void_p, C.c_void_p]
+        L.par_oracle_shadow.restype = C.c_int
+        L.par_oracle_shadow.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p, C.c_void_p]
+        L.par_oracle_render_mt.restype = C.c_int
+        L.par_oracle_render_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_int]
+        L.par_oracle_bin.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.par_oracle_primary.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int]
+        L.par_oracle_shade.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int]
+        L.par_oracle_debug_line.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_void_p]
+        L.par_oracle_tile_floor.argtypes = [C.c_void_p]
+
+    def tile_floor(self):
+        s = np.zeros(1, dtype=T.SPRITE)
+        self.lib.par_oracle_tile_floor(T.ptr(s))
+        return s
+
+    def color_scale(self, rgba, v):
+        r = self.lib.par_oracle_color_scale(T.Color(*rgba), C.c_float(v))
+        return (r.red, r.green, r.blue, r.alpha)
+
+    def normalize(self, v):
+        r = self.lib.par_oracle_normalize(_V3(*[float(x) for x in v]))
+        return np.array([r.x, r.y, r.z], dtype=np.float32)
+
+    def intersect(self, box, ray):
+        return int(self.lib.par_oracle_intersect(T.ptr(box), T.ptr(ray)))
+
+    def bin(self, params, aabbs, grid=None):
+        grid = grid or GridArrays(params)
+        g = grid.c()
+        self.lib.par_oracle_bin(C.byref(params), T.ptr(aabbs), len(aabbs), C.byref(g))
+        return grid
+
+    def primary(self, params, grid, sprites, sprite_ids=None, rows=None):
+        W, H = params.width, params.height
+        r0, r1 = rows or (0, H)
+        gbuf = np.zeros(H * W, dtype=T.PIXEL)
+        pal = np.zeros(H * W, dtype=np.uint8)
+        g = grid.c()
+        self.lib.par_oracle_primary(C.byref(params), C.byref(g), T.ptr(sprites), T.ptr(sprite_ids), T.ptr(gbuf),
+                                    T.ptr(pal), r0, r1)
+        return gbuf, pal
+
+    def shadow(self, grid, start, end, start_entity, ray):
+        g = grid.c()
+        return int(self.lib.par_oracle_shadow(C.byref(g), *[int(v) for v in start], *[int(v) for v in end],
+                                              int(start_entity), T.ptr(ray), None))
+
+    def shade(self, params, grid, gbuf, light, rows=None):
+        W, H = params.width, params.height
+        r0, r1 = rows or (0, H)
+        fb = np.zeros(H * W, dtype=T.COLOR)
+        br = np.zeros(H * W, dtype=np.float32)
+        lit = np.zeros(H * W, dtype=np.uint8)
+        g = grid.c()
+        self.lib.par_oracle_shade(C.byref(params), C.byref(g), T.ptr(gbuf), T.ptr(light), T.ptr(fb), T.ptr(br),
+                                  T.ptr(lit), r0, r1)
+        return fb, br, lit
+
+    def render(self, params, aabbs, sprites, light, sprite_ids=None, nthreads=1,
+               planes=("fb", "gbuf", "palidx", "brightness", "lit")):
+        """alt:690-760 for one frame. Returns a dict of the requested planes (flat, row-major)."""
+        n = params.width * params.height
+        dt = {"fb": T.COLOR, "gbuf": T.PIXEL, "palidx": np.uint8, "brightness": np.float32, "lit": np.uint8}
+        out = {k: (np.zeros(n, dtype=dt[k]) if k in planes else None) for k in dt}
+        rc = self.lib.par_oracle_render_mt(C.byref(params), T.ptr(aabbs), len(aabbs), T.ptr(sprites),
+                                           T.ptr(sprite_ids), T.ptr(light), T.ptr(out["fb"]), T.ptr(out["gbuf"]),
+                                           T.ptr(out["palidx"]), T.ptr(out["brightness"]), T.ptr(out["lit"]),
+                                           int(nthreads))
+        if rc != 0:
+            raise RuntimeError("par_oracle_render failed (bad parameters or allocation)")
+        return {k: v for k, v in out.items() if v is not None}
+
+    def debug_line(self, params, gbuf, light, mouse_x, mouse_y, fb):
+        self.lib.par_oracle_debug_line(C.byref(params), T.ptr(gbuf), T.ptr(light), mouse_x, mouse_y, T.ptr(fb))
+
+
+class Reference:
+    """The reference's own hot-path functions at its hard-coded 480x320x320 / bin 40 (alt:116-123)."""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "_ref", "libref_path.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = L = C.CDLL(path)
+        L.ref_scene_create.restype = C.c_void_p
+        L.ref_scene_create.argtypes = [C.c_void_p, C.c_int]
+        L.ref_scene_free.argtypes = [C.c_void_p]
+        L.ref_scene_set_aabb.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_bin.argtypes = [C.c_void_p] * 4
+        L.ref_primary.argtypes = [C.c_void_p] * 5
+        L.ref_shade.argtypes = [C.c_void_p] * 8
+        L.ref_shadow.restype = C.c_int
+        L.ref_shadow.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]
+        L.ref_intersect.restype = C.c_int
+        L.ref_intersect.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_color_scale.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.ref_normalize.argtypes = [C.c_void_p, C.c_void_p]
+        L.ref_tile_sprite.argtypes = [C.c_void_p]
+        L.ref_palette.argtypes = [C.c_void_p]
+        c = (C.c_int * 8)()
+        L.ref_consts(c)
+        self.consts = dict(zip(("bin", "width", "height", "length", "gx", "gy", "gz", "slots"), c))
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "libref_path.so"))
+
+    def params(self):
+        return T.default_params(self.consts["width"], self.consts["height"], self.consts["length"],
+                                self.consts["bin"])
+
+    def tile_sprite(self):
+        s = np.zeros(1, dtype=T.SPRITE)
+        self.lib.ref_tile_sprite(T.ptr(s))
+        return s
+
+    def palette(self):
+        p = np.zeros(4, dtype=T.COLOR)
+        self.lib.ref_palette(T.ptr(p))
+        return p
+
+    def color_scale(self, rgba, v):
+        a = np.array([tuple(rgba)], dtype=T.COLOR)
+        o = np.zeros(1, dtype=T.COLOR)
+        self.lib.ref_color_scale(T.ptr(a), C.c_float(v), T.ptr(o))
+        return tuple(int(x) for x in o[0])
+
+    def normalize(self, v):
+        a = np.array([tuple(float(x) for x in v)], dtype=T.VEC3)
+        o = np.zeros(1, dtype=T.VEC3)
+        self.lib.ref_normalize(T.ptr(a), T.ptr(o))
+        return np.array([o["x"][0], o["y"][0], o["z"][0]], dtype=np.float32)
+
+    def intersect(self, box, ray):
+        return int(self.lib.ref_intersect(T.ptr(box), T.ptr(ray)))
+
+    def scene(self, aabbs):
+        return self.lib.ref_scene_create(T.ptr(aabbs), len(aabbs))
+
+    def scene_set_aabb(self, h, i, aabb):
+        self.lib.ref_scene_set_aabb(h, i, T.ptr(aabb))
+
+    def scene_free(self, h):
+        self.lib.ref_scene_free(h)
+
+    def bin(self, h, grid):
+        self.lib.ref_bin(h, T.ptr(grid.count), T.ptr(grid.map), T.ptr(grid.bins))
+
+    def primary(self, h, grid):
+        gbuf = np.zeros(self.consts["width"] * self.consts["height"], dtype=T.PIXEL)
+        self.lib.ref_primary(h, T.ptr(grid.count), T.ptr(grid.map), T.ptr(grid.bins), T.ptr(gbuf))
+        return gbuf
+
+    def shadow(self, grid, start, end, start_entity, ray):
+        return int(self.lib.ref_shadow(T.ptr(grid.count), T.ptr(grid.map), T.ptr(grid.bins),
+                                       *[int(v) for v in start], *[int(v) for v in end], int(start_entity),
+                                       T.ptr(ray)))
+
+    def shade(self, grid, gbuf, light):
+        n = self.consts["width"] * self.consts["height"]
+        fb = np.zeros(n, dtype=T.COLOR)
+        br = np.zeros(n, dtype=np.float32)
+        lit = np.zeros(n, dtype=np.uint8)
+        self.lib.ref_shade(T.ptr(grid.count), T.ptr(grid.map), T.ptr(grid.bins), T.ptr(gbuf), T.ptr(light),
+                           T.ptr(fb), T.ptr(br), T.ptr(lit))
+        return fb, br, lit

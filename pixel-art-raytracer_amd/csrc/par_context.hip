@@ -1,0 +1,655 @@
+// par_context.hip — the renderer context and the C ABI (include/par_raytracer.h) over the HIP kernels.
+//
+// Host-side mirror of what the reference's `main` does around its render call (alt = src/alternative.cpp):
+// it owns the work arrays (alt:503-517), takes the scene the caller built (alt:517-599, 619-626), and runs one
+// frame = bin + trace + shade (alt:690-760) per render call. There is no CPU rendering path in this library.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "par_internal.h"
+
+struct par_context {
+    par_params params{};
+    int device = 0;
+    int gx = 0, gy = 0, gz = 0, volume = 0;
+    hipStream_t stream = nullptr;  // used by the synchronous host-buffer entry points
+
+    // host mirrors
+    std::vector<par_aabb> h_aabbs;
+    std::vector<int32_t> h_pairs;  // (entity, bin) pairs each entity inserts, alt:243-267
+    int64_t total_pairs = 0;
+    int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
+    bool have_light = false, have_entities = false;
+    par_light light{};
+    int set = 0;  // head/count/node set the NEXT frame uses
+
+    // device
+    par_aabb* d_aabbs = nullptr;
+    int32_t* d_sprite_ids = nullptr;
+    par_sprite* d_sprites = nullptr;
+    par_color* d_palette = nullptr;
+    unsigned long long* d_ray_counter = nullptr;
+    par_grid_dev grid{};
+    int aabb_capacity = 0;
+
+    // device output planes for the host-buffer entry points
+    void* d_out[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t d_out_bytes[5] = {0, 0, 0, 0, 0};
+
+    // hipGraph path: one executable graph per grid set, a pinned staging area they copy from
+    hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+    hipGraph_t graph[2] = {nullptr, nullptr};
+    par_aabb* pin_aabbs = nullptr;
+    par_frame_dyn* pin_dyn = nullptr;
+    par_frame_dyn* d_dyn = nullptr;
+    int graph_set = 0;
+
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    par_frame_stats stats{};
+    unsigned last_flags = 0;
+    std::string err;
+};
+
+namespace {
+
+constexpr size_t kPlaneElem[5] = {sizeof(par_color), sizeof(par_pixel), 1, sizeof(float), 1};
+
+int fail(par_context* c, int status, const std::string& msg) {
+    if (c) c->err = msg;
+    return status;
+}
+
+int hip_fail(par_context* c, hipError_t e, const char* what) {
+    return fail(c, e == hipErrorOutOfMemory ? PAR_ERR_OOM : PAR_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define PAR_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+// (entity, bin) pairs one AABB inserts: the cull and range math of alt:202-240.
+int64_t pairs_of(const par_context* c, const par_aabb& a) {
+    const int W = c->params.width, H = c->params.height, L = c->params.length, B = c->params.bin_size;
+    const int minx = a.px, miny = a.py, minz = a.pz;
+    const int maxx = minx + a.ex, maxy = miny + a.ey, maxz = minz + a.ez;
+    if ((maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) || (maxz < -a.ez - B) ||
+        (minz > L + B)) {
+        return 0;
+    }
+    const int x0 = std::max(0, minx / B), y0 = std::max(0, (H - maxy - maxz) / B), z0 = std::max(0, minz / B);
+    const int x1 = std::min(c->gx, (maxx + B - 1) / B), y1 = std::min(c->gy, (H - miny - minz + B - 1) / B);
+    const int z1 = std::min(c->gz, (maxz + B - 1) / B);
+    if (x1 <= x0 || y1 <= y0 || z1 <= z0) return 0;
+    return (int64_t)(x1 - x0) * (y1 - y0) * (z1 - z0);
+}
+
+bool extent_ok(const par_aabb& a) {
+    // The sprite is 20 wide and 40 tall (alt:330, spr:67-71): texel row = (ey + ez) - 1 at most, column < ex.
+    return a.ex >= 0 && a.ey >= 0 && a.ez >= 0 && a.ex <= PAR_SPRITE_W && (int)a.ey + (int)a.ez <= PAR_SPRITE_H;
+}
+
+void free_pool(par_context* c) {
+    for (int s = 0; s < 2; s++) {
+        if (c->grid.node_entity[s]) (void)hipFree(c->grid.node_entity[s]);
+        if (c->grid.node_next[s]) (void)hipFree(c->grid.node_next[s]);
+        if (c->grid.node_bin[s]) (void)hipFree(c->grid.node_bin[s]);
+        c->grid.node_entity[s] = c->grid.node_next[s] = c->grid.node_bin[s] = nullptr;
+    }
+    c->grid.capacity = 0;
+}
+
+// Wipe both head/count sets and the node counters (context creation, and whenever the node pool is replaced and
+// the record of which bins the previous frame touched is lost with it).
+int reset_grid(par_context* ctx) {
+    for (int s = 0; s < 2; s++) {
+        PAR_HIP(hipMemsetAsync(ctx->grid.head[s], 0, (size_t)ctx->volume * sizeof(int32_t), ctx->stream));
+        PAR_HIP(hipMemsetAsync(ctx->grid.count[s], 0, (size_t)ctx->volume, ctx->stream));
+    }
+    PAR_HIP(hipMemsetAsync(ctx->grid.node_counter, 0, 2 * sizeof(int32_t), ctx->stream));
+    PAR_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->set = 0;
+    return PAR_OK;
+}
+
+int ensure_pool(par_context* ctx, int64_t pairs) {
+    if (pairs <= ctx->grid.capacity) return PAR_OK;
+    if (ctx->graph_exec[0]) return fail(ctx, PAR_ERR_UNSUPPORTED, "node pool would grow under a captured graph; capture again");
+    int64_t cap = std::max<int64_t>(pairs + pairs / 2, 1 << 16);
+    if (cap > 0x3FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "too many (entity, bin) pairs");
+    PAR_HIP(hipDeviceSynchronize());
+    free_pool(ctx);
+    for (int s = 0; s < 2; s++) {
+        PAR_HIP(hipMalloc(&ctx->grid.node_entity[s], (size_t)cap * sizeof(int32_t)));
+        PAR_HIP(hipMalloc(&ctx->grid.node_next[s], (size_t)cap * sizeof(int32_t)));
+        PAR_HIP(hipMalloc(&ctx->grid.node_bin[s], (size_t)cap * sizeof(int32_t)));
+    }
+    ctx->grid.capacity = (int32_t)cap;
+    return reset_grid(ctx);
+}
+
+void drop_graphs(par_context* c) {
+    for (int s = 0; s < 2; s++) {
+        if (c->graph_exec[s]) (void)hipGraphExecDestroy(c->graph_exec[s]);
+        if (c->graph[s]) (void)hipGraphDestroy(c->graph[s]);
+        c->graph_exec[s] = nullptr;
+        c->graph[s] = nullptr;
+    }
+}
+
+par_frame_dyn make_dyn(const par_context* c, const par_light& l) {
+    const int B = c->params.bin_size, H = c->params.height;
+    par_frame_dyn d;
+    d.lx = l.x; d.ly = l.y; d.lz = l.z;
+    d.lbx = l.x / B;                // alt:729
+    d.lby = (H - l.y - l.z) / B;    // alt:730-731
+    d.lbz = l.z / B;                // alt:732
+    return d;
+}
+
+int check_rows(par_context* ctx, int row_begin, int row_end) {
+    if (row_begin < 0 || row_end > ctx->params.height || row_begin >= row_end) {
+        return fail(ctx, PAR_ERR_INVALID_ARG, "rows must satisfy 0 <= row_begin < row_end <= height");
+    }
+    return PAR_OK;
+}
+
+int check_ready(par_context* ctx) {
+    if (ctx->n_sprites <= 0) return fail(ctx, PAR_ERR_NOT_READY, "par_set_sprites has not been called");
+    if (!ctx->have_entities) return fail(ctx, PAR_ERR_NOT_READY, "par_set_entities has not been called");
+    if (!ctx->have_light) return fail(ctx, PAR_ERR_NOT_READY, "par_set_light has not been called");
+    if (ctx->max_sprite_id >= ctx->n_sprites) return fail(ctx, PAR_ERR_SPRITE_ID, "an entity names a sprite that was not uploaded");
+    return PAR_OK;
+}
+
+par_render_args make_render_args(const par_context* c, int set, int row_begin, int row_end, const par_outputs& out,
+                                 unsigned flags, bool dyn_from_device) {
+    par_render_args a{};
+    const int B = c->params.bin_size;
+    a.W = c->params.width; a.H = c->params.height; a.B = B;
+    a.row_begin = row_begin; a.row_end = row_end;
+    a.by_begin = row_begin / B;
+    a.tile_rows = std::min(B, PAR_TILE_PIXELS / B);
+    a.subs = (B + a.tile_rows - 1) / a.tile_rows;
+    a.magic_b = (uint32_t)((1ull << 32) / (uint64_t)B + 1ull);
+    a.ambient = c->params.ambient;
+    a.background = c->params.background;
+    a.flags = flags;
+    a.n_sprites = c->n_sprites;
+    a.dyn = make_dyn(c, c->light);
+    a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;
+    a.count = c->grid.count[set];
+    a.slots = c->grid.slots;
+    a.sprites = c->d_sprites;
+    a.sprite_ids = c->d_sprite_ids;
+    a.palette = c->d_palette;
+    a.out = out;
+    a.ray_counter = c->d_ray_counter;
+    return a;
+}
+
+par_bin_args make_bin_args(const par_context* c, int set) {
+    par_bin_args b{};
+    b.W = c->params.width; b.H = c->params.height; b.L = c->params.length; b.B = c->params.bin_size;
+    b.n = c->n_entities;
+    b.set = set;
+    b.aabbs = c->d_aabbs;
+    return b;
+}
+
+// Enqueue one frame (alt:690-760) on `stream` using grid set `set`.
+int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, int row_end, const par_outputs& out,
+                  unsigned flags, bool graph_mode, hipEvent_t* ev) {
+    const par_bin_args b = make_bin_args(ctx, set);
+    const par_render_args r = make_render_args(ctx, set, row_begin, row_end, out, flags, graph_mode);
+    if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
+        PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
+    }
+    if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
+    PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
+    // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
+    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
+    if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
+    PAR_HIP(par_launch_render(ctx->grid, r, stream));
+    if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
+    return PAR_OK;
+}
+
+int render_to_host(par_context* ctx, int row_begin, int row_end, const par_outputs* host_out, unsigned flags) {
+    if (!ctx || !host_out) return fail(ctx, PAR_ERR_INVALID_ARG, "null argument");
+    int rc = check_rows(ctx, row_begin, row_end);
+    if (rc != PAR_OK) return rc;
+    rc = check_ready(ctx);
+    if (rc != PAR_OK) return rc;
+    PAR_HIP(hipSetDevice(ctx->device));
+    void* host[5] = {host_out->fb, host_out->gbuf, host_out->palidx, host_out->brightness, host_out->lit};
+    const size_t n = (size_t)(row_end - row_begin) * ctx->params.width;
+    void* dev[5];
+    for (int i = 0; i < 5; i++) {
+        dev[i] = nullptr;
+        if (!host[i]) continue;
+        const size_t bytes = n * kPlaneElem[i];
+        if (ctx->d_out_bytes[i] < bytes) {
+            if (ctx->d_out[i]) PAR_HIP(hipFree(ctx->d_out[i]));
+            ctx->d_out[i] = nullptr;
+            ctx->d_out_bytes[i] = 0;
+            PAR_HIP(hipMalloc(&ctx->d_out[i], bytes));
+            ctx->d_out_bytes[i] = bytes;
+        }
+        dev[i] = ctx->d_out[i];
+    }
+    par_outputs d{(par_color*)dev[0], (par_pixel*)dev[1], (uint8_t*)dev[2], (float*)dev[3], (uint8_t*)dev[4]};
+    rc = enqueue_frame(ctx, ctx->stream, ctx->set, row_begin, row_end, d, flags, false, nullptr);
+    if (rc != PAR_OK) return rc;
+    ctx->set ^= 1;
+    ctx->last_flags = flags;
+    for (int i = 0; i < 5; i++) {
+        if (host[i]) PAR_HIP(hipMemcpyAsync(host[i], dev[i], n * kPlaneElem[i], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PAR_HIP(hipStreamSynchronize(ctx->stream));
+    return PAR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* par_last_error(const par_context* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int par_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int par_create(const par_params* params, int device, par_context** out) {
+    if (!params || !out) return PAR_ERR_INVALID_ARG;
+    *out = nullptr;
+    const par_params& p = *params;
+    if (p.width <= 0 || p.height <= 0 || p.length <= 0 || p.bin_size <= 0 || p.width > 32767 || p.height > 32767 ||
+        p.length > 32767 || !(p.ambient >= 0.f && p.ambient <= 1.f) || p.palette_size <= 0 ||
+        p.palette_size > PAR_MAX_PALETTE) {
+        return PAR_ERR_INVALID_ARG;  // coordinates are `short` in the reference (alt:12-38); Color*ambient must fit u8
+    }
+    int gx, gy, gz;
+    par_grid_dims(&p, &gx, &gy, &gz);
+    if (p.bin_size < 4 || p.bin_size > PAR_TILE_PIXELS || gx > PAR_MAX_GRID_DIM || gy > PAR_MAX_GRID_DIM ||
+        gz > PAR_MAX_GRID_DIM || (int64_t)gx * gy * gz > 0x3FFFFFFF) {
+        return PAR_ERR_UNSUPPORTED;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PAR_ERR_NO_DEVICE;
+    if (device < 0) {
+        if (hipGetDevice(&device) != hipSuccess) return PAR_ERR_NO_DEVICE;
+    }
+    if (device >= ndev) return PAR_ERR_INVALID_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PAR_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return PAR_ERR_NO_DEVICE;  // kernels are built for gfx950 only
+
+    par_context* ctx = new (std::nothrow) par_context;
+    if (!ctx) return PAR_ERR_OOM;
+    ctx->params = p;
+    ctx->device = device;
+    ctx->gx = gx; ctx->gy = gy; ctx->gz = gz; ctx->volume = gx * gy * gz;
+    ctx->grid.gx = gx; ctx->grid.gy = gy; ctx->grid.gz = gz; ctx->grid.volume = ctx->volume;
+    ctx->stats.shadow_rays = -1; ctx->stats.ms_bin = -1.f; ctx->stats.ms_render = -1.f;
+    auto bail = [&](hipError_t e) {
+        int rc = e == hipErrorOutOfMemory ? PAR_ERR_OOM : PAR_ERR_HIP;
+        par_destroy(ctx);
+        return rc;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+    for (int s = 0; s < 2; s++) {
+        if ((e = hipMalloc(&ctx->grid.head[s], (size_t)ctx->volume * sizeof(int32_t))) != hipSuccess) return bail(e);
+        if ((e = hipMalloc(&ctx->grid.count[s], (size_t)ctx->volume)) != hipSuccess) return bail(e);
+    }
+    if ((e = hipMalloc(&ctx->grid.slots, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.node_counter, 2 * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->d_palette, PAR_MAX_PALETTE * sizeof(par_color))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->d_ray_counter, sizeof(unsigned long long))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->d_dyn, sizeof(par_frame_dyn))) != hipSuccess) return bail(e);
+    if ((e = hipMemcpy(ctx->d_palette, p.palette, PAR_MAX_PALETTE * sizeof(par_color), hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
+    if ((e = hipMemset(ctx->grid.slots, 0, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
+    for (int i = 0; i < 3; i++) {
+        if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return bail(e);
+    }
+    if (reset_grid(ctx) != PAR_OK) {
+        par_destroy(ctx);
+        return PAR_ERR_HIP;
+    }
+    if (ensure_pool(ctx, 1) != PAR_OK) {
+        par_destroy(ctx);
+        return PAR_ERR_OOM;
+    }
+    *out = ctx;
+    return PAR_OK;
+}
+
+void par_destroy(par_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    drop_graphs(ctx);
+    free_pool(ctx);
+    for (int s = 0; s < 2; s++) {
+        if (ctx->grid.head[s]) (void)hipFree(ctx->grid.head[s]);
+        if (ctx->grid.count[s]) (void)hipFree(ctx->grid.count[s]);
+    }
+    void* ptrs[] = {ctx->grid.slots, ctx->grid.node_counter, ctx->d_palette, ctx->d_ray_counter, ctx->d_dyn,
+                    ctx->d_aabbs, ctx->d_sprite_ids, ctx->d_sprites};
+    for (void* p : ptrs) {
+        if (p) (void)hipFree(p);
+    }
+    for (int i = 0; i < 5; i++) {
+        if (ctx->d_out[i]) (void)hipFree(ctx->d_out[i]);
+    }
+    if (ctx->pin_aabbs) (void)hipHostFree(ctx->pin_aabbs);
+    if (ctx->pin_dyn) (void)hipHostFree(ctx->pin_dyn);
+    for (int i = 0; i < 3; i++) {
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) {
+    if (!ctx || !sprites || n_sprites <= 0) return fail(ctx, PAR_ERR_INVALID_ARG, "sprites");
+    for (int s = 0; s < n_sprites; s++) {
+        for (int t = 0; t < PAR_SPRITE_TEXELS; t++) {
+            const int c = sprites[s].color[t];
+            if (c < 0 || c >= ctx->params.palette_size) {  // color_palette[...] out of bounds is UB at alt:353
+                return fail(ctx, PAR_ERR_SPRITE_ID, "sprite palette index outside the palette");
+            }
+        }
+    }
+    PAR_HIP(hipSetDevice(ctx->device));
+    PAR_HIP(hipDeviceSynchronize());
+    if (ctx->d_sprites) PAR_HIP(hipFree(ctx->d_sprites));
+    ctx->d_sprites = nullptr;
+    ctx->n_sprites = 0;
+    PAR_HIP(hipMalloc(&ctx->d_sprites, (size_t)n_sprites * sizeof(par_sprite)));
+    PAR_HIP(hipMemcpy(ctx->d_sprites, sprites, (size_t)n_sprites * sizeof(par_sprite), hipMemcpyHostToDevice));
+    ctx->n_sprites = n_sprites;
+    return PAR_OK;
+}
+
+int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* sprite_ids, int n) {
+    if (!ctx || n < 0 || (n > 0 && !aabbs)) return fail(ctx, PAR_ERR_INVALID_ARG, "entities");
+    int max_id = 0;
+    for (int i = 0; i < n; i++) {
+        if (!extent_ok(aabbs[i])) {
+            return fail(ctx, PAR_ERR_EXTENT, "entity " + std::to_string(i) + ": extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
+        }
+        if (sprite_ids) {
+            if (sprite_ids[i] < 0) return fail(ctx, PAR_ERR_SPRITE_ID, "negative sprite id");
+            max_id = std::max(max_id, (int)sprite_ids[i]);
+        }
+    }
+    PAR_HIP(hipSetDevice(ctx->device));
+    PAR_HIP(hipDeviceSynchronize());
+    drop_graphs(ctx);
+    std::vector<int32_t> pairs((size_t)n);
+    int64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        const int64_t k = pairs_of(ctx, aabbs[i]);
+        if (k > 0x7FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "entity spans too many bins");
+        pairs[(size_t)i] = (int32_t)k;
+        total += k;
+    }
+    int rc = ensure_pool(ctx, total);
+    if (rc != PAR_OK) return rc;
+    if (n > ctx->aabb_capacity) {
+        if (ctx->d_aabbs) PAR_HIP(hipFree(ctx->d_aabbs));
+        ctx->d_aabbs = nullptr;
+        ctx->aabb_capacity = 0;
+        PAR_HIP(hipMalloc(&ctx->d_aabbs, (size_t)std::max(n, 1) * sizeof(par_aabb)));
+        ctx->aabb_capacity = std::max(n, 1);
+    }
+    if (ctx->d_sprite_ids) PAR_HIP(hipFree(ctx->d_sprite_ids));
+    ctx->d_sprite_ids = nullptr;
+    if (n > 0) PAR_HIP(hipMemcpy(ctx->d_aabbs, aabbs, (size_t)n * sizeof(par_aabb), hipMemcpyHostToDevice));
+    if (sprite_ids && n > 0 && max_id > 0) {  // all-zero ids need no table
+        PAR_HIP(hipMalloc(&ctx->d_sprite_ids, (size_t)n * sizeof(int32_t)));
+        PAR_HIP(hipMemcpy(ctx->d_sprite_ids, sprite_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    ctx->h_aabbs.assign(aabbs, aabbs + n);
+    ctx->h_pairs.swap(pairs);
+    ctx->total_pairs = total;
+    ctx->n_entities = n;
+    ctx->max_sprite_id = max_id;
+    ctx->have_entities = true;
+    ctx->stats.entities = n;
+    return PAR_OK;
+}
+
+int par_set_entities_ref_layout(par_context* ctx, const par_aabb* aabbs, const par_sprite* sprite_per_entity, int n) {
+    if (!ctx || n < 0 || (n > 0 && (!aabbs || !sprite_per_entity))) return fail(ctx, PAR_ERR_INVALID_ARG, "entities");
+    // The reference stores one 16 000-byte Sprite per entity (alt:95,107). Keep each distinct sprite once.
+    std::unordered_map<std::string, int32_t> seen;
+    std::vector<par_sprite> table;
+    std::vector<int32_t> ids((size_t)n);
+    for (int i = 0; i < n; i++) {
+        std::string key(reinterpret_cast<const char*>(&sprite_per_entity[i]), sizeof(par_sprite));
+        auto it = seen.find(key);
+        if (it == seen.end()) {
+            it = seen.emplace(std::move(key), (int32_t)table.size()).first;
+            table.push_back(sprite_per_entity[i]);
+        }
+        ids[(size_t)i] = it->second;
+    }
+    if (table.empty()) {
+        par_sprite s;
+        par_sprite_tile_floor(&s);
+        table.push_back(s);
+    }
+    int rc = par_set_sprites(ctx, table.data(), (int)table.size());
+    if (rc != PAR_OK) return rc;
+    return par_set_entities(ctx, aabbs, ids.data(), n);
+}
+
+int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) {
+    if (!ctx || !aabbs || first < 0 || n < 0 || !ctx->have_entities || first + n > ctx->n_entities) {
+        return fail(ctx, PAR_ERR_INVALID_ARG, "update range outside the uploaded entities");
+    }
+    int64_t total = ctx->total_pairs;
+    for (int i = 0; i < n; i++) {
+        if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
+    }
+    std::vector<int32_t> np((size_t)n);
+    for (int i = 0; i < n; i++) {
+        np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i]);
+        total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
+    }
+    PAR_HIP(hipSetDevice(ctx->device));
+    int rc = ensure_pool(ctx, total);
+    if (rc != PAR_OK) return rc;
+    // stream-ordered behind any frame still in flight on the context stream
+    PAR_HIP(hipMemcpyAsync(ctx->d_aabbs + first, aabbs, (size_t)n * sizeof(par_aabb), hipMemcpyHostToDevice, ctx->stream));
+    PAR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++) {
+        ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
+        ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
+    }
+    ctx->total_pairs = total;
+    return PAR_OK;
+}
+
+int par_set_light(par_context* ctx, const par_light* light) {
+    if (!ctx || !light) return fail(ctx, PAR_ERR_INVALID_ARG, "light");
+    ctx->light = *light;
+    ctx->have_light = true;
+    return PAR_OK;
+}
+
+int par_render(par_context* ctx, const par_outputs* host_out, unsigned flags) {
+    if (!ctx) return PAR_ERR_INVALID_ARG;
+    return render_to_host(ctx, 0, ctx->params.height, host_out, flags);
+}
+
+int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outputs* host_out, unsigned flags) {
+    return render_to_host(ctx, row_begin, row_end, host_out, flags);
+}
+
+int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
+                      unsigned flags) {
+    if (!ctx || !device_out) return fail(ctx, PAR_ERR_INVALID_ARG, "null argument");
+    int rc = check_rows(ctx, row_begin, row_end);
+    if (rc != PAR_OK) return rc;
+    rc = check_ready(ctx);
+    if (rc != PAR_OK) return rc;
+    rc = enqueue_frame(ctx, (hipStream_t)stream, ctx->set, row_begin, row_end, *device_out, flags, false, nullptr);
+    if (rc != PAR_OK) return rc;
+    ctx->set ^= 1;
+    ctx->last_flags = flags;
+    return PAR_OK;
+}
+
+int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int row_end,
+                            const par_outputs* device_out, unsigned flags, par_frame_stats* stats) {
+    if (!ctx || !device_out) return fail(ctx, PAR_ERR_INVALID_ARG, "null argument");
+    int rc = check_rows(ctx, row_begin, row_end);
+    if (rc != PAR_OK) return rc;
+    rc = check_ready(ctx);
+    if (rc != PAR_OK) return rc;
+    rc = enqueue_frame(ctx, (hipStream_t)stream, ctx->set, row_begin, row_end, *device_out, flags, false, ctx->ev);
+    if (rc != PAR_OK) return rc;
+    ctx->set ^= 1;
+    ctx->last_flags = flags;
+    PAR_HIP(hipEventSynchronize(ctx->ev[2]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_bin, ctx->ev[0], ctx->ev[1]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[1], ctx->ev[2]));
+    if (stats) return par_get_stats(ctx, stats);
+    return PAR_OK;
+}
+
+int par_graph_capture(par_context* ctx, void* stream_v, int row_begin, int row_end, const par_outputs* device_out,
+                      unsigned flags) {
+    if (!ctx || !device_out) return fail(ctx, PAR_ERR_INVALID_ARG, "null argument");
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (!stream) return fail(ctx, PAR_ERR_INVALID_ARG, "graph capture needs a non-default stream");
+    int rc = check_rows(ctx, row_begin, row_end);
+    if (rc != PAR_OK) return rc;
+    rc = check_ready(ctx);
+    if (rc != PAR_OK) return rc;
+    PAR_HIP(hipSetDevice(ctx->device));
+    PAR_HIP(hipDeviceSynchronize());
+    drop_graphs(ctx);
+    // Head-room for moving primitives: pair counts of later frames are only bounded by the pool.
+    rc = ensure_pool(ctx, ctx->total_pairs * 2 + 4096);
+    if (rc != PAR_OK) return rc;
+    if (!ctx->pin_aabbs) {
+        PAR_HIP(hipHostMalloc(&ctx->pin_aabbs, (size_t)std::max(ctx->aabb_capacity, 1) * sizeof(par_aabb), hipHostMallocDefault));
+        PAR_HIP(hipHostMalloc(&ctx->pin_dyn, sizeof(par_frame_dyn), hipHostMallocDefault));
+    }
+    std::memcpy(ctx->pin_aabbs, ctx->h_aabbs.data(), (size_t)ctx->n_entities * sizeof(par_aabb));
+    *ctx->pin_dyn = make_dyn(ctx, ctx->light);
+    // The frame alternates between the two grid sets, and a captured kernel node bakes its pointers: one graph
+    // per set, launched alternately.
+    for (int s = 0; s < 2; s++) {
+        PAR_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        hipError_t e = hipMemcpyAsync(ctx->d_aabbs, ctx->pin_aabbs, (size_t)ctx->n_entities * sizeof(par_aabb),
+                                      hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_dyn, ctx->pin_dyn, sizeof(par_frame_dyn), hipMemcpyHostToDevice, stream);
+        int erc = PAR_OK;
+        if (e == hipSuccess) erc = enqueue_frame(ctx, stream, s, row_begin, row_end, *device_out, flags & ~PAR_RENDER_COUNT_RAYS, true, nullptr);
+        hipGraph_t g = nullptr;
+        hipError_t e2 = hipStreamEndCapture(stream, &g);
+        if (e != hipSuccess) return hip_fail(ctx, e, "graph capture memcpy");
+        if (erc != PAR_OK) return erc;
+        if (e2 != hipSuccess) return hip_fail(ctx, e2, "hipStreamEndCapture");
+        ctx->graph[s] = g;
+        PAR_HIP(hipGraphInstantiate(&ctx->graph_exec[s], g, nullptr, nullptr, 0));
+    }
+    ctx->graph_set = ctx->set;
+    return PAR_OK;
+}
+
+int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, const par_light* light) {
+    if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
+    if (n < 0 || first < 0 || first + n > ctx->n_entities || (n > 0 && !aabbs)) return fail(ctx, PAR_ERR_INVALID_ARG, "stage range");
+    int64_t total = ctx->total_pairs;
+    for (int i = 0; i < n; i++) {
+        if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
+        total += pairs_of(ctx, aabbs[i]) - ctx->h_pairs[(size_t)(first + i)];
+    }
+    if (total > ctx->grid.capacity) return fail(ctx, PAR_ERR_UNSUPPORTED, "staged frame exceeds the captured node pool; capture again");
+    for (int i = 0; i < n; i++) {
+        ctx->h_pairs[(size_t)(first + i)] = (int32_t)pairs_of(ctx, aabbs[i]);
+        ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
+        ctx->pin_aabbs[first + i] = aabbs[i];
+    }
+    ctx->total_pairs = total;
+    if (light) {
+        ctx->light = *light;
+        *ctx->pin_dyn = make_dyn(ctx, *light);
+    }
+    return PAR_OK;
+}
+
+int par_graph_launch(par_context* ctx, void* stream) {
+    if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
+    PAR_HIP(hipGraphLaunch(ctx->graph_exec[ctx->set], (hipStream_t)stream));
+    ctx->set ^= 1;
+    return PAR_OK;
+}
+
+int par_pick(par_context* ctx, int x, int y, par_pixel* out) {
+    if (!ctx || !out || x < 0 || y < 0 || x >= ctx->params.width || y >= ctx->params.height) {
+        return fail(ctx, PAR_ERR_INVALID_ARG, "pick outside the view");
+    }
+    std::vector<par_pixel> row((size_t)ctx->params.width);
+    par_outputs o{nullptr, row.data(), nullptr, nullptr, nullptr};
+    int rc = render_to_host(ctx, y, y + 1, &o, 0);
+    if (rc != PAR_OK) return rc;
+    *out = row[(size_t)x];  // `mouse_pixel`, alt:380-382
+    return PAR_OK;
+}
+
+int par_get_stats(par_context* ctx, par_frame_stats* stats) {
+    if (!ctx || !stats) return fail(ctx, PAR_ERR_INVALID_ARG, "stats");
+    PAR_HIP(hipSetDevice(ctx->device));
+    PAR_HIP(hipDeviceSynchronize());
+    ctx->stats.entities = ctx->n_entities;
+    ctx->stats.bin_insertions = ctx->total_pairs;
+    ctx->stats.shadow_rays = -1;
+    if (ctx->last_flags & PAR_RENDER_COUNT_RAYS) {
+        unsigned long long v = 0;
+        PAR_HIP(hipMemcpy(&v, ctx->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost));
+        ctx->stats.shadow_rays = (int64_t)v;
+    }
+    *stats = ctx->stats;
+    return PAR_OK;
+}
+
+int par_read_grid(par_context* ctx, int32_t* count, int32_t* map, par_aabb* bins) {
+    if (!ctx || !count || !map || !bins) return fail(ctx, PAR_ERR_INVALID_ARG, "grid buffers");
+    PAR_HIP(hipSetDevice(ctx->device));
+    PAR_HIP(hipDeviceSynchronize());
+    const int last = ctx->set ^ 1;  // the set the last frame used
+    std::vector<uint8_t> c((size_t)ctx->volume);
+    std::vector<par_slot> s((size_t)ctx->volume * PAR_SLOTS);
+    PAR_HIP(hipMemcpy(c.data(), ctx->grid.count[last], c.size(), hipMemcpyDeviceToHost));
+    PAR_HIP(hipMemcpy(s.data(), ctx->grid.slots, s.size() * sizeof(par_slot), hipMemcpyDeviceToHost));
+    std::memset(map, 0, (size_t)ctx->volume * PAR_SLOTS * sizeof(int32_t));
+    std::memset(bins, 0, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_aabb));
+    for (int b = 0; b < ctx->volume; b++) {
+        count[b] = c[(size_t)b];
+        for (int k = 0; k < c[(size_t)b]; k++) {
+            const par_slot& r = s[(size_t)b * PAR_SLOTS + k];
+            map[(size_t)b * PAR_SLOTS + k] = r.entity;
+            bins[(size_t)b * PAR_SLOTS + k] = par_aabb{r.px, r.py, r.pz, r.ex, r.ey, r.ez, {0, 0}};
+        }
+    }
+    return PAR_OK;
+}
+
+}  // extern "C"

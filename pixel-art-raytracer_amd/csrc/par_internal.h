@@ -1,0 +1,82 @@
+// par_internal.h — device-side data layout and kernel launch interface (internal to libpar_raytracer.so).
+#ifndef PAR_INTERNAL_H
+#define PAR_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "par_raytracer.h"
+
+// One slot of a hash bin on the device: the reference keeps `AABB bins[G*8]` and `int map[G*8]` side by side
+// (alt:503-509); the AABB's 4 bytes of tail padding (alt:86-88) carry the entity index here, so a whole bin
+// (8 slots) is exactly one 128-byte line.
+struct par_slot {
+    int16_t px, py, pz;
+    int16_t ex, ey, ez;
+    int32_t entity;
+};
+static_assert(sizeof(par_slot) == 16, "slot record must stay 16 bytes");
+
+// Kernel geometry (see DESIGN.md "render kernel").
+constexpr int PAR_NT = 320;          // threads per workgroup = 5 wavefronts
+constexpr int PAR_KPT = 5;           // pixels per thread -> up to 1600 pixels (one 40x40 bin footprint) per workgroup
+constexpr int PAR_TILE_PIXELS = PAR_NT * PAR_KPT;
+constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count the LDS column list is sized for
+constexpr int PAR_MAX_ENTRIES = 512;    // column slot records staged in LDS (the rest is read from HBM/L2)
+constexpr int PAR_MAX_OCC = 1024;       // shadow-occluder records staged in LDS per round
+constexpr int PAR_CHAIN_ITERS = PAR_NT / 8;  // walk iterations per probe chunk (8 lanes per iteration, 7 used)
+
+// Per-frame values that change without the scene being re-uploaded. In the hipGraph path they live in device memory
+// (updated by a memcpy node); otherwise they travel as kernel arguments.
+struct par_frame_dyn {
+    int32_t lx, ly, lz;     // lights[0] position (alt:712-714)
+    int32_t lbx, lby, lbz;  // its bin (alt:729-732)
+};
+
+struct par_grid_dev {
+    int32_t gx, gy, gz, volume;
+    int32_t* head[2];         // [volume] node index + 1 of the most recent insertion, 0 = none
+    uint8_t* count[2];        // [volume] visible count = insertions & 7 (alt:262-264)
+    par_slot* slots;          // [volume * 8]
+    int32_t* node_entity[2];  // [capacity]
+    int32_t* node_next[2];    // [capacity]
+    int32_t* node_bin[2];     // [capacity]
+    int32_t* node_counter;    // [2]
+    int32_t capacity;
+};
+
+struct par_render_args {
+    int32_t W, H, B;
+    int32_t row_begin, row_end;    // rows rendered by this launch
+    int32_t by_begin;              // first bin row touched
+    int32_t tile_rows;             // rows per workgroup tile (R)
+    int32_t subs;                  // tiles per bin row = ceil(B / R)
+    uint32_t magic_b;              // floor(p / B) == __umulhi(p, magic_b) for p < PAR_TILE_PIXELS
+    float ambient;
+    uint32_t background;           // gray level (alt:281)
+    uint32_t flags;
+    int32_t n_sprites;
+    par_frame_dyn dyn;             // used when dyn_ptr == nullptr
+    const par_frame_dyn* dyn_ptr;  // graph path
+    const uint8_t* count;
+    const par_slot* slots;
+    const par_sprite* sprites;
+    const int32_t* sprite_ids;     // nullable
+    const par_color* palette;
+    par_outputs out;               // device pointers, addressing (row_begin, 0)
+    unsigned long long* ray_counter;
+};
+
+struct par_bin_args {
+    int32_t W, H, L, B;
+    int32_t n;
+    int32_t set;  // which head/count/node set this frame uses
+    const par_aabb* aabbs;
+};
+
+// Launchers (par_kernels.hip). All asynchronous on `stream`.
+hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
+hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
+
+#endif

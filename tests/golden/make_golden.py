@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz|json by running the REFERENCE's own functions (oracle/_ref/libref_path.so).
+
+Run in the build container only (the reference cannot travel): `python tests/golden/make_golden.py`.
+The fixtures hold data only — inputs (AABBs, lights, rays) and the reference's outputs (SHA-256 of each output
+buffer, small planes verbatim) — never reference source.
+
+  ref_frames.json / ref_frames.npz   random + crafted scenes at the reference's 480x320x320: per-case hashes of the
+                                     grid (visible slots), G-buffer, RGBA frame, brightness and lit planes.
+  ref_units.npz                      AABB::intersect / Color*float / normalize / trace_hash_for_light vectors,
+                                     including +-inf and NaN inverse directions.
+  appendix_b.json                    whole-program known answers recorded by the survey.
+"""
+import ctypes as C
+import hashlib
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle.oracle import GridArrays, Reference  # noqa: E402
+
+T = importlib.import_module("pixel-art-raytracer_amd.types")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def visible_hash(grid):
+    """Hash of the defined part of the hash grid: count[], and map/bins of slots below count."""
+    h = hashlib.sha256()
+    h.update(grid.count.tobytes())
+    live = np.nonzero(grid.count)[0]
+    for b in live:
+        for s in range(int(grid.count[b])):
+            h.update(grid.map[b * T.SLOTS + s].tobytes())
+            h.update(grid.bins[b * T.SLOTS + s].tobytes()[:12])
+    return h.hexdigest()
+
+
+def random_scene(rng, n, style):
+    a = np.zeros(n, dtype=T.AABB)
+    if style == "uniform":          # SURVEY §8d synthetic distribution
+        a["px"] = rng.integers(-20, 480, n)
+        a["py"] = rng.integers(-20, 200, n)
+        a["pz"] = rng.integers(-20, 320, n)
+    elif style == "floor":          # grid-aligned floor + random boxes on top: high coverage, wrapped bins
+        k = 0
+        for i in range(24):
+            for j in range(16):
+                if k < n:
+                    a[k]["px"], a[k]["py"], a[k]["pz"] = i * 20, 0, j * 20
+                    k += 1
+        a["px"][k:] = rng.integers(0, 460, n - k)
+        a["py"][k:] = rng.integers(20, 120, n - k)
+        a["pz"][k:] = rng.integers(0, 300, n - k)
+    elif style == "clump":          # many boxes in few bins: counter wraps at 8 (alt:262-264)
+        a["px"] = rng.integers(180, 260, n)
+        a["py"] = rng.integers(0, 60, n)
+        a["pz"] = rng.integers(60, 140, n)
+    elif style == "edges":          # straddling every view edge, some fully outside (cull alt:212-219)
+        a["px"] = rng.choice([-25, -20, -10, 0, 470, 479, 480, 500], n)
+        a["py"] = rng.integers(-60, 380, n)
+        a["pz"] = rng.choice([-70, -61, -60, -40, -20, 0, 300, 319, 340, 360, 361, 380], n)
+    a["ex"] = a["ey"] = a["ez"] = 20
+    if style == "uniform":
+        # a few non-cubic extents the 20x40 sprite can still express (ex<=20, ey+ez<=40)
+        m = rng.random(n) < 0.2
+        a["ex"][m] = rng.integers(1, 21, int(m.sum()))
+        a["ey"][m] = rng.integers(0, 25, int(m.sum()))
+        a["ez"][m] = np.minimum(40 - a["ey"][m], rng.integers(0, 25, int(m.sum())))
+    return a
+
+
+CASES = [
+    # name, n, style, light (x,y,z) — the light keeps every probed flat index inside the reference's arrays
+    ("uniform64", 64, "uniform", (300, 160, 80)),
+    ("uniform256", 256, "uniform", (300, 160, 80)),
+    ("uniform1024", 1024, "uniform", (300, 160, 80)),
+    ("floor600", 600, "floor", (300, 160, 80)),
+    ("floor600_lowlight", 600, "floor", (100, 30, 200)),
+    ("clump200", 200, "clump", (400, 100, 40)),
+    ("edges300", 300, "edges", (240, 120, 120)),
+    ("uniform512_axis_light", 512, "uniform", (240, 0, 0)),   # many zero light-vector components -> inf/NaN slabs
+    ("floor500_light_in_floor", 500, "floor", (200, 10, 100)),
+    ("empty", 0, "uniform", (300, 160, 80)),
+    ("single", 1, "floor", (300, 160, 80)),
+]
+
+
+def frames(ref):
+    rng = np.random.default_rng(20250225)
+    meta, arrays = {}, {}
+    for name, n, style, lpos in CASES:
+        aabbs = random_scene(rng, n, style)
+        light = T.make_light(*lpos)
+        h = ref.scene(aabbs)
+        grid = GridArrays(ref.params())
+        ref.bin(h, grid)
+        gbuf = ref.primary(h, grid)
+        fb, br, lit = ref.shade(grid, gbuf, light)
+        ref.scene_free(h)
+        arrays[name + "_aabbs"] = aabbs.view(np.int16).reshape(-1, 8)
+        arrays[name + "_light"] = light.view(np.int16)
+        meta[name] = {
+            "n": n, "style": style, "light": list(lpos),
+            "grid_visible": visible_hash(grid), "gbuf": sha(gbuf), "fb": sha(fb), "brightness": sha(br),
+            "lit": sha(lit), "lit_count": int(lit.sum()),
+            "background": int((gbuf["color"]["red"] == 127).sum()),
+        }
+        print(name, meta[name]["lit_count"], meta[name]["background"])
+    np.savez_compressed(os.path.join(HERE, "ref_frames.npz"), **arrays)
+    with open(os.path.join(HERE, "ref_frames.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+
+
+def units(ref):
+    rng = np.random.default_rng(7)
+    n = 4096
+    boxes = np.zeros(n, dtype=T.AABB)
+    for k in ("px", "py", "pz"):
+        boxes[k] = rng.integers(-100, 500, n)
+    for k in ("ex", "ey", "ez"):
+        boxes[k] = rng.integers(0, 41, n)
+    rays = np.zeros(n, dtype=T.RAY)
+    special = np.array([np.inf, -np.inf, np.nan, 0.0, -0.0, 1.0, -1.0, 3.0, 1e-3, -2.5], dtype=np.float32)
+    for k in ("inv_x", "inv_y", "inv_z"):
+        v = (1.0 / rng.uniform(-1, 1, n)).astype(np.float32)
+        m = rng.random(n) < 0.35
+        v[m] = rng.choice(special, int(m.sum()))
+        rays[k] = v
+    for k in ("ox", "oy", "oz"):
+        rays[k] = rng.integers(-50, 480, n)
+    # make many origins coincide with a box plane so that 0 * inf = NaN really occurs
+    m = rng.random(n) < 0.3
+    rays["ox"][m] = boxes["px"][m]
+    m = rng.random(n) < 0.3
+    rays["oy"][m] = boxes["py"][m] + boxes["ey"][m]
+    # half of the rays aim at (a point inside) their box, as shadow rays do: inv = 1 / L1-normalised direction
+    aim = rng.random(n) < 0.5
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d = np.stack([boxes["px"] + rng.integers(0, 41, n) // 2 - rays["ox"],
+                      boxes["py"] + rng.integers(0, 41, n) // 2 - rays["oy"],
+                      boxes["pz"] + rng.integers(0, 41, n) // 2 - rays["oz"]], axis=1).astype(np.float32)
+        length = (np.abs(d[:, 0]) + np.abs(d[:, 1])) + np.abs(d[:, 2])
+        inv = (np.float32(1.0) / (d / length[:, None])).astype(np.float32)
+    for j, k in enumerate(("inv_x", "inv_y", "inv_z")):
+        rays[k][aim] = inv[aim, j]
+    hit = np.array([ref.intersect(boxes[i:i + 1], rays[i:i + 1]) for i in range(n)], dtype=np.uint8)
+
+    cs_in = np.zeros((2048, 5), dtype=np.float32)
+    cs_in[:, :4] = rng.integers(0, 256, (2048, 4))
+    cs_in[:, 4] = rng.uniform(0, 1, 2048).astype(np.float32)
+    cs_in[:64, 4] = np.linspace(0, 1, 64, dtype=np.float32)
+    cs_out = np.array([ref.color_scale(tuple(int(c) for c in r[:4]), float(r[4])) for r in cs_in], dtype=np.uint8)
+
+    nv = rng.integers(-500, 500, (2048, 3)).astype(np.float32)
+    nv[:32] = 0
+    nv[32:64, 0] = 0
+    nv_out = np.stack([ref.normalize(v) for v in nv])
+
+    np.savez_compressed(os.path.join(HERE, "ref_units.npz"), boxes=boxes.view(np.int16).reshape(-1, 8),
+                        rays=rays.view(np.uint8).reshape(-1, 20), hit=hit, cs_in=cs_in, cs_out=cs_out, nv=nv,
+                        nv_out=nv_out)
+    print("intersect hits", int(hit.sum()), "of", n)
+
+
+def appendix_b():
+    """SHA-256 of buffers produced by the unmodified reference whole program."""
+    data = {
+        "frame0_rgba_with_debug_line": "5bf7b18d8bdde8e6d411b3d1ffbd733f5280f2723c734c3241dbe74c33783d98",
+        "frame0_gbuf": "f2be3c1cd7f6a83956c23650578efffb07b7cd812d411c130b801ac1ab94dfa2",
+        "frame0_grid_dump": "312b45b762c6b783c463f13377de4790fb1f84d9b3556496dfd226e6372d9fb7",
+        "key_script": "RRRRUUUUhhhhjjPP",
+        "script_frames": {
+            "1": "69e4ee6adde9c86cdaa09f9702502b22b310f46c1ab9f105f71f83cb5a3cf3e7",
+            "4": "1a7bdc1fe6516c88a9791cc7467be22a98967a42f4464eab1b0f3591cd4957ac",
+            "8": "1c7fa1662b6d271f6970c8e89a1d1c522d579ed19660c5f5dcbd6fb7cef89f55",
+            "12": "4dadf06c5910ca2a0073fee53486d160921db5a931366cecc55fa3a0c97af7ce",
+            "16": "433e25ed14042d96b87ad045e32c3699dc86838d0d4e87c86869b2ccff4063ff",
+        },
+        "stats": {"entities": 162308, "cull_survivors": 766, "bin_insertions": 1095, "background_pixels": 3200,
+                  "lit_pixels": 130682, "distinct_visible_entities": 335, "distinct_colors": 210,
+                  "palette_pixels": {"100": 77568, "140": 8176, "200": 42840, "240": 21816}},
+        "spot": {"0,0": [0, 1, 0, 100, 121, 199, 153628], "160,240": [0, 1, 0, 100, 21, 139, 3841],
+                 "319,479": [0, 0, -1, 140, 1, 0, 7349]},
+    }
+    with open(os.path.join(HERE, "appendix_b.json"), "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    ref = Reference()
+    frames(ref)
+    units(ref)
+    appendix_b()

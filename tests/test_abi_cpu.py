@@ -1,0 +1,85 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/par_raytracer.h declares, the
+host-side scene helpers match the reference's scene, and rendering without a GPU fails loudly (no fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol(par):
+    L = par.lib()
+    header = open(os.path.join(ROOT, "include", "par_raytracer.h")).read()
+    declared = set(re.findall(r"^(?:const char\*|void|int)\s+(par_[a-z_0-9]+)\(", header, flags=re.M))
+    assert declared == set(par.ABI_SYMBOLS), declared ^ set(par.ABI_SYMBOLS)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_default_params_and_grid(par, T):
+    p = T.Params()
+    par.lib().par_default_params(ctypes.byref(p))
+    q = T.default_params()
+    assert bytes(p) == bytes(q)
+    gx, gy, gz = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    assert par.lib().par_grid_dims(ctypes.byref(p), ctypes.byref(gx), ctypes.byref(gy), ctypes.byref(gz)) == 0
+    assert (gx.value, gy.value, gz.value) == (12, 8, 8) == p.grid_dims()  # alt:120-122
+    p.width, p.height, p.length = 4096, 4096, 4096
+    assert p.grid_dims() == (103, 103, 103)
+
+
+def test_tile_sprite_matches_oracle_restatement(par, oracle):
+    assert par.tile_floor().tobytes() == oracle.tile_floor().tobytes()
+
+
+def test_graybox_scene(par, appendix_b):
+    a = par.scene_graybox(480, 320)
+    assert len(a) == appendix_b["stats"]["entities"]
+    assert (a["px"].min(), a["px"].max()) == (0, 9580) and (a["pz"].min(), a["pz"].max()) == (-5860, 6380)
+    assert tuple(a[0][["px", "py", "pz", "ex", "ey", "ez"]]) == (240, 36, 80, 20, 20, 20)  # player, alt:520-523
+
+
+def test_synthetic_scene_is_deterministic(par):
+    a, l = par.scene_synthetic(1024, 4096, 4096, 4096, 12345)
+    b, _ = par.scene_synthetic(1024, 4096, 4096, 4096, 12345)
+    assert a.tobytes() == b.tobytes()
+    assert tuple(l[0][["x", "y", "z"]]) == (2560, 2048, 1024)
+    assert a["px"].min() >= -20 and a["px"].max() < 4096 and a["py"].max() < 200 and a["pz"].max() < 4096
+
+    # splitmix64(12345): first three draws, independent restatement
+    def sm(state):
+        mask = (1 << 64) - 1
+        state = (state + 0x9E3779B97F4A7C15) & mask
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        return state, z ^ (z >> 31)
+
+    s = 12345
+    s, r0 = sm(s)
+    s, r1 = sm(s)
+    s, r2 = sm(s)
+    assert (int(a[0]["px"]), int(a[0]["py"]), int(a[0]["pz"])) == (-20 + r0 % 4116, -20 + r1 % 220, -20 + r2 % 4116)
+
+
+def test_debug_line_matches_oracle(par, oracle, T):
+    params = T.default_params()
+    light = T.make_light(480, 160, 80)
+    gbuf = np.zeros(480 * 320, dtype=T.PIXEL)
+    gbuf[0]["y"], gbuf[0]["z"] = 121, 199
+    fa = np.zeros(480 * 320, dtype=T.COLOR)
+    fb = np.zeros(480 * 320, dtype=T.COLOR)
+    oracle.debug_line(params, gbuf, light, 0, 0, fa)
+    par.debug_line(params, gbuf[0:1], 0, light, fb)
+    assert fa.tobytes() == fb.tobytes() and fa["alpha"].sum() > 0
+
+
+def test_no_gpu_means_loud_failure(par, T):
+    if par.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(par.ParError) as e:
+        par.Renderer(T.default_params())
+    assert e.value.status == 2  # PAR_ERR_NO_DEVICE: there is no CPU rendering path
