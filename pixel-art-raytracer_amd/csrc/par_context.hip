@@ -279,7 +279,7 @@ int par_create(const par_params* params, int device, par_context** out) {
     }
     int gx, gy, gz;
     par_grid_dims(&p, &gx, &gy, &gz);
-    if (p.bin_size < 4 || p.bin_size > PAR_TILE_PIXELS || gx > PAR_MAX_GRID_DIM || gy > PAR_MAX_GRID_DIM ||
+    if (p.bin_size < 8 || p.bin_size > PAR_TILE_PIXELS || gx > PAR_MAX_GRID_DIM || gy > PAR_MAX_GRID_DIM ||
         gz > PAR_MAX_GRID_DIM || (int64_t)gx * gy * gz > 0x3FFFFFFF) {
         return PAR_ERR_UNSUPPORTED;
     }

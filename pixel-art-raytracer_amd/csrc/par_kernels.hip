@@ -198,7 +198,10 @@ __device__ __forceinline__ uint32_t color_scale(uint32_t c, float v) {
     return r | (g << 8) | (b << 16) | (c & 0xFF000000u);
 }
 
-__device__ __forceinline__ int pack_key(int sy, int sz) { return ((sy + 32768) << 16) | ((sz + 32768) & 0xFFFF); }
+// (sy, sz) of a start bin as one sortable word; bin coordinates are far inside +-32768 (positions are `short`).
+__device__ __forceinline__ int pack_key(int sy, int sz) {
+    return (int)((((uint32_t)(sy + 16384) & 0x7FFFu) << 16) | ((uint32_t)(sz + 32768) & 0xFFFFu));
+}
 
 __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_render_args a) {
     __shared__ RenderShared sm;
@@ -394,8 +397,8 @@ __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_rend
         if (cur == INT_MAX) break;  // uniform
 
         const int sx = bx;  // world_x / B, alt:724
-        const int sy = (cur >> 16) - 32768;
-        const int sz = (int)(int16_t)((cur & 0xFFFF) - 32768);
+        const int sy = (cur >> 16) - 16384;
+        const int sz = (cur & 0xFFFF) - 32768;
         bool mine[PAR_KPT];
 #pragma unroll
         for (int k = 0; k < PAR_KPT; k++) mine[k] = pend[k] && key[k] == cur;
