@@ -203,24 +203,106 @@ __device__ __forceinline__ int pack_key(int sy, int sz) {
     return (int)((((uint32_t)(sy + 16384) & 0x7FFFu) << 16) | ((uint32_t)(sz + 32768) & 0xFFFFu));
 }
 
+// Trunc-toward-zero division by the bin size through a precomputed reciprocal: exact for |n| * B < 2^32
+// (|n| <= 3 * 32767 here and B <= 1600).
+__device__ __forceinline__ int div_bin(int n, uint32_t magic) {
+    const int q = (int)__umulhi((uint32_t)(n < 0 ? -n : n), magic);
+    return n < 0 ? -q : q;
+}
+
+// A tile no primitive can cover: every requested plane gets its background constant.
+__device__ __forceinline__ void fill_background_tile(const par_render_args& a, int r0, int r1, int c0, int tw,
+                                                     uint32_t out_rgba, uint32_t bg_rgba, float ambient) {
+    const int tid = threadIdx.x;
+    const int W = a.W, rows = r1 - r0;
+    const size_t base = (size_t)(r0 - a.row_begin) * W + c0;
+    if (a.out.fb) {
+        uint32_t* fb = reinterpret_cast<uint32_t*>(a.out.fb);
+        if (((W | c0 | tw) & 3) == 0 && (reinterpret_cast<uintptr_t>(fb) & 15) == 0) {
+            const int nvec = tw >> 2;  // 16-byte stores: 4 pixels per lane
+            const uint4 v = make_uint4(out_rgba, out_rgba, out_rgba, out_rgba);
+            for (int i = tid; i < rows * nvec; i += PAR_NT) {
+                const int ry = i / nvec, vx = i - ry * nvec;
+                *reinterpret_cast<uint4*>(fb + base + (size_t)ry * W + vx * 4) = v;
+            }
+        } else {
+            for (int i = tid; i < rows * tw; i += PAR_NT) {
+                const int ry = i / tw, x = i - ry * tw;
+                fb[base + (size_t)ry * W + x] = out_rgba;
+            }
+        }
+    }
+    if (a.out.palidx) {
+        uint8_t* pal = a.out.palidx;
+        if (((W | c0 | tw) & 7) == 0 && (reinterpret_cast<uintptr_t>(pal) & 7) == 0) {
+            const int nvec = tw >> 3;  // 8-byte stores: 8 pixels per lane
+            const uint2 v = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            for (int i = tid; i < rows * nvec; i += PAR_NT) {
+                const int ry = i / nvec, vx = i - ry * nvec;
+                *reinterpret_cast<uint2*>(pal + base + (size_t)ry * W + vx * 8) = v;
+            }
+        } else {
+            for (int i = tid; i < rows * tw; i += PAR_NT) {
+                const int ry = i / tw, x = i - ry * tw;
+                pal[base + (size_t)ry * W + x] = PAR_PALIDX_BACKGROUND;
+            }
+        }
+    }
+    if (a.out.brightness || a.out.gbuf) {
+        par_pixel px;
+        px.normal = par_vec3{0.f, 0.f, 0.f};
+        px.color.red = px.color.green = px.color.blue = (uint8_t)(bg_rgba & 0xFF);
+        px.color.alpha = 0;
+        px.y = 0; px.z = 0; px.entity_index = 0;
+        for (int i = tid; i < rows * tw; i += PAR_NT) {
+            const int ry = i / tw, x = i - ry * tw;
+            const size_t o = base + (size_t)ry * W + x;
+            if (a.out.brightness) a.out.brightness[o] = ambient;
+            if (a.out.gbuf) a.out.gbuf[o] = px;
+        }
+    }
+}
+
 __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_render_args a) {
     __shared__ RenderShared sm;
     const int tid = threadIdx.x;
     const int W = a.W, H = a.H, B = a.B;
 
     // ---- tile decode (uniform) ----------------------------------------------------------------------------
-    const int bx = blockIdx.x % g.gx;
-    const int trow = blockIdx.x / g.gx;
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2. Tiles that are neighbours in x share
+    // 128-byte lines of the frame (a 40-pixel tile row is 160 bytes), so consecutive logical tiles are given to
+    // ONE XCD: its L2 then merges the partial lines before they are written back. Bijective for any grid size.
+    int t_id;
+    {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        const int q = nb >> 3, rem = nb & 7, xcd = b & 7;
+        t_id = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+    }
+    const int bx = t_id % g.gx;
+    const int trow = t_id / g.gx;
     const int by = a.by_begin + trow / a.subs;
     const int sub = trow - (trow / a.subs) * a.subs;
     const int tile_r0 = by * B + sub * a.tile_rows;
-    int r0 = max(tile_r0, a.row_begin);
-    int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
+    const int r0 = max(tile_r0, a.row_begin);
+    const int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
     if (r0 >= r1) return;
     const int c0 = bx * B;
     const int tw = min(B, W - c0);
-    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
     const bool trace_bg = (a.flags & PAR_RENDER_TRACE_BACKGROUND) != 0 || a.out.lit != nullptr;
+    const float ambient = a.ambient;
+    const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
+    const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
+
+    // ---- phase 0: empty column -> the tile is background (alt:281, 735): constant fill, wide coalesced stores ---
+    if (!trace_bg) {
+        int any = 0;
+        for (int t = tid; t < g.gz; t += PAR_NT) any |= a.count[col_base + t];
+        if (!__syncthreads_or(any)) {
+            fill_background_tile(a, r0, r1, c0, tw, color_scale(bg_rgba, ambient), bg_rgba, ambient);
+            return;
+        }
+    }
+    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
 
     if (tid == 0) {
         sm.gkey[0] = INT_MAX;
@@ -228,7 +310,6 @@ __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_rend
     }
 
     // ---- phase 1: the column (bx, by, *) -> ordered list of non-empty bins and their slot records in LDS -----
-    const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
     int nb_base = 0, ent_base = 0;
     for (int t0 = 0; t0 < g.gz; t0 += PAR_NT) {
         const int t = t0 + tid;
@@ -277,7 +358,7 @@ __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_rend
     }
 
     // ---- phase 2: primary ray, alt:271-397 -----------------------------------------------------------------
-    if (n_nb > 0) {
+    if (n_nb > 0 && !(a.flags & (1u << 29))) {  // bit 29: ablation, no primary pass
 #pragma unroll
         for (int k = 0; k < PAR_KPT; k++) {
             const int i = col[k];
@@ -331,8 +412,6 @@ __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_rend
     }
 
     // ---- phase 3: shading set-up, alt:704-735 --------------------------------------------------------------
-    const float ambient = a.ambient;
-    const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
     float inv_x[PAR_KPT], inv_y[PAR_KPT], inv_z[PAR_KPT];
     float b_lit[PAR_KPT];       // brightness if the light is reached: min(1, diffuse + ambient), alt:745-758
     uint32_t rgba[PAR_KPT];     // palette colour of the texel (alt:352-354) or the background gray
@@ -354,20 +433,27 @@ __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_rend
         }
         pend[k] = valid[k] && (hit[k] || trace_bg);
         lit[k] = true;
-        const int wx = col[k], wy = p_y[k], wz = p_z[k];  // alt:707-709
-        // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
-        const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
-        const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
-        const float tx = dx / len, ty = dy / len, tz = dz / len;
-        inv_x[k] = 1.f / tx;  // alt:717-719
-        inv_y[k] = 1.f / ty;
-        inv_z[k] = 1.f / tz;
-        const float dot = nx * tx + ny * ty + nz * tz;           // alt:746-747 (no contraction)
-        const float diffuse = std_max(0.f, dot);                 // alt:745
-        b_lit[k] = std_min(1.f, diffuse + ambient);              // alt:758
-        const int sy = (H - wy - wz) / B;                        // alt:725-726
-        const int sz = wz / B;                                   // alt:727
-        key[k] = pack_key(sy, sz);
+        // Background pixels whose shadow ray is skipped keep brightness = ambient: with a zero normal
+        // min(1, max(0, 0 * t) + ambient) is ambient whether or not the light is reached (SURVEY a-6).
+        inv_x[k] = inv_y[k] = inv_z[k] = 0.f;
+        b_lit[k] = ambient;
+        key[k] = INT_MAX;
+        if (pend[k]) {
+            const int wx = col[k], wy = p_y[k], wz = p_z[k];  // alt:707-709
+            // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
+            const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
+            const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
+            const float tx = dx / len, ty = dy / len, tz = dz / len;
+            inv_x[k] = 1.f / tx;  // alt:717-719
+            inv_y[k] = 1.f / ty;
+            inv_z[k] = 1.f / tz;
+            const float dot = nx * tx + ny * ty + nz * tz;           // alt:746-747 (no contraction)
+            const float diffuse = std_max(0.f, dot);                 // alt:745
+            b_lit[k] = std_min(1.f, diffuse + ambient);              // alt:758
+            const int sy = div_bin(H - wy - wz, a.magic_b);          // alt:725-726
+            const int sz = div_bin(wz, a.magic_b);                   // alt:727
+            key[k] = pack_key(sy, sz);
+        }
         n_traced += pend[k] ? 1 : 0;
     }
     if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
@@ -384,6 +470,7 @@ __global__ __launch_bounds__(PAR_NT) void render_kernel(par_grid_dev g, par_rend
     // occupied bins it finds are staged in LDS and every pixel of the group slab-tests that list. The result of
     // trace_hash_for_light is an OR over probes, hence independent of probe order and of duplicate probes.
     for (int iter = 0;; iter++) {
+        if (a.flags & (1u << 30)) break;  // ablation: no shadow pass (timing experiments only)
         int mykey = INT_MAX;
 #pragma unroll
         for (int k = 0; k < PAR_KPT; k++) {

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Timing experiments on the render kernel (GPU box): ablation flags, empty scene, dense floor scene."""
+import importlib, os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+par = importlib.import_module("pixel-art-raytracer_amd")
+T = par.types
+
+def run(name, params, aabbs, light, flags=0, planes=("fb", "palidx"), n=30):
+    W, H = params.width, params.height
+    r = par.Renderer(params, 0)
+    r.set_scene(aabbs, par.tile_floor(), light)
+    bufs = {"fb": torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda"),
+            "palidx": torch.zeros(W * H, dtype=torch.uint8, device="cuda"),
+            "lit": torch.zeros(W * H, dtype=torch.uint8, device="cuda")}
+    ptrs = {k: bufs[k].data_ptr() for k in planes}
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        r.render_device(ptrs, stream=s, flags=flags, timed=True)
+    ms = [r.render_device(ptrs, stream=s, flags=flags, timed=True).ms_render for _ in range(n)]
+    mb = [r.render_device(ptrs, stream=s, flags=flags, timed=True).ms_bin for _ in range(5)]
+    print(f"{name:50s} render {np.mean(ms)*1e3:9.1f} us (min {np.min(ms)*1e3:8.1f})  bin {np.mean(mb)*1e3:7.1f} us  pairs {r.stats().bin_insertions}")
+    r.close()
+
+W = H = L = 4096
+p = T.default_params(W, H, L)
+a, l = par.scene_synthetic(1024, W, H, L, 12345)
+run("4096 synthetic1024", p, a, l)
+run("4096 synthetic1024 no-shadow", p, a, l, flags=1 << 30)
+run("4096 synthetic1024 no-primary no-shadow", p, a, l, flags=(1 << 30) | (1 << 29))
+run("4096 synthetic1024 trace-bg", p, a, l, flags=1)
+run("4096 empty scene (fill only)", p, a[:0], l)
+run("4096 fb only", p, a, l, planes=("fb",))
+# dense: full floor of 20x20x20 tiles
+rows = [(i * 20, 0, j * 20, 20, 20, 20) for i in range(W // 20) for j in range(L // 20)]
+fl = T.make_aabbs(rows)
+run("4096 full floor (41943 prims)", p, fl, l)
+run("4096 full floor no-shadow", p, fl, l, flags=1 << 30)
+p2 = T.default_params(2048, 2048, 2048)
+a2, l2 = par.scene_synthetic(256, 2048, 2048, 2048, 12345)
+run("2048 synthetic256", p2, a2, l2)
+p3 = T.default_params()
+run("480x320 default graybox", p3, par.scene_graybox(), T.make_light(480, 160, 80))
