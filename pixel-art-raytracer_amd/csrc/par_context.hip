@@ -48,7 +48,7 @@ struct par_context {
     par_frame_dyn* d_dyn = nullptr;
     int graph_set = 0;
 
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     par_frame_stats stats{};
     unsigned last_flags = 0;
     std::string err;
@@ -111,7 +111,9 @@ int reset_grid(par_context* ctx) {
     for (int s = 0; s < 2; s++) {
         PAR_HIP(hipMemsetAsync(ctx->grid.head[s], 0, (size_t)ctx->volume * sizeof(int32_t), ctx->stream));
         PAR_HIP(hipMemsetAsync(ctx->grid.count[s], 0, (size_t)ctx->volume, ctx->stream));
+        PAR_HIP(hipMemsetAsync(ctx->grid.colflag[s], 0, (size_t)ctx->gx * ctx->gy * sizeof(int32_t), ctx->stream));
     }
+    PAR_HIP(hipMemsetAsync(ctx->grid.ncols, 0, sizeof(int32_t), ctx->stream));
     PAR_HIP(hipMemsetAsync(ctx->grid.node_counter, 0, 2 * sizeof(int32_t), ctx->stream));
     PAR_HIP(hipStreamSynchronize(ctx->stream));
     ctx->set = 0;
@@ -174,9 +176,12 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     const int B = c->params.bin_size;
     a.W = c->params.width; a.H = c->params.height; a.B = B;
     a.row_begin = row_begin; a.row_end = row_end;
-    a.by_begin = row_begin / B;
-    a.tile_rows = std::min(B, PAR_TILE_PIXELS / B);
+    a.by_lo = row_begin / B;
+    a.by_hi = (row_end - 1) / B;
+    a.tile_rows = PAR_NT / B;
     a.subs = (B + a.tile_rows - 1) / a.tile_rows;
+    // every ray traced (as the reference does), or the lit plane requested: every column goes through the tracer
+    a.dense = ((flags & PAR_RENDER_TRACE_BACKGROUND) || out.lit) ? 1 : 0;
     a.magic_b = (uint32_t)((1ull << 32) / (uint64_t)B + 1ull);
     a.ambient = c->params.ambient;
     a.background = c->params.background;
@@ -185,6 +190,7 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.dyn = make_dyn(c, c->light);
     a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;
     a.count = c->grid.count[set];
+    a.colflag = c->grid.colflag[set];
     a.slots = c->grid.slots;
     a.sprites = c->d_sprites;
     a.sprite_ids = c->d_sprite_ids;
@@ -194,8 +200,10 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     return a;
 }
 
-par_bin_args make_bin_args(const par_context* c, int set) {
+par_bin_args make_bin_args(const par_context* c, int set, int row_begin, int row_end) {
     par_bin_args b{};
+    b.by_lo = row_begin / c->params.bin_size;
+    b.by_hi = (row_end - 1) / c->params.bin_size;
     b.W = c->params.width; b.H = c->params.height; b.L = c->params.length; b.B = c->params.bin_size;
     b.n = c->n_entities;
     b.set = set;
@@ -206,7 +214,7 @@ par_bin_args make_bin_args(const par_context* c, int set) {
 // Enqueue one frame (alt:690-760) on `stream` using grid set `set`.
 int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, int row_end, const par_outputs& out,
                   unsigned flags, bool graph_mode, hipEvent_t* ev) {
-    const par_bin_args b = make_bin_args(ctx, set);
+    const par_bin_args b = make_bin_args(ctx, set, row_begin, row_end);
     const par_render_args r = make_render_args(ctx, set, row_begin, row_end, out, flags, graph_mode);
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
@@ -216,7 +224,10 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
     PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
-    PAR_HIP(par_launch_render(ctx->grid, r, stream));
+    PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
+    // occupied columns <= (entity, bin) pairs; future graph replays are only bounded by the pool
+    PAR_HIP(par_launch_render(ctx->grid, r, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
 }
@@ -279,7 +290,7 @@ int par_create(const par_params* params, int device, par_context** out) {
     }
     int gx, gy, gz;
     par_grid_dims(&p, &gx, &gy, &gz);
-    if (p.bin_size < 8 || p.bin_size > PAR_TILE_PIXELS || gx > PAR_MAX_GRID_DIM || gy > PAR_MAX_GRID_DIM ||
+    if (p.bin_size < PAR_MIN_BIN || p.bin_size > PAR_MAX_BIN || gx > PAR_MAX_GRID_DIM || gy > PAR_MAX_GRID_DIM ||
         gz > PAR_MAX_GRID_DIM || (int64_t)gx * gy * gz > 0x3FFFFFFF) {
         return PAR_ERR_UNSUPPORTED;
     }
@@ -299,7 +310,7 @@ int par_create(const par_params* params, int device, par_context** out) {
     ctx->device = device;
     ctx->gx = gx; ctx->gy = gy; ctx->gz = gz; ctx->volume = gx * gy * gz;
     ctx->grid.gx = gx; ctx->grid.gy = gy; ctx->grid.gz = gz; ctx->grid.volume = ctx->volume;
-    ctx->stats.shadow_rays = -1; ctx->stats.ms_bin = -1.f; ctx->stats.ms_render = -1.f;
+    ctx->stats.shadow_rays = -1; ctx->stats.ms_bin = -1.f; ctx->stats.ms_fill = -1.f; ctx->stats.ms_render = -1.f;
     auto bail = [&](hipError_t e) {
         int rc = e == hipErrorOutOfMemory ? PAR_ERR_OOM : PAR_ERR_HIP;
         par_destroy(ctx);
@@ -311,7 +322,10 @@ int par_create(const par_params* params, int device, par_context** out) {
     for (int s = 0; s < 2; s++) {
         if ((e = hipMalloc(&ctx->grid.head[s], (size_t)ctx->volume * sizeof(int32_t))) != hipSuccess) return bail(e);
         if ((e = hipMalloc(&ctx->grid.count[s], (size_t)ctx->volume)) != hipSuccess) return bail(e);
+        if ((e = hipMalloc(&ctx->grid.colflag[s], (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     }
+    if ((e = hipMalloc(&ctx->grid.col_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.ncols, sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.slots, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.node_counter, 2 * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->d_palette, PAR_MAX_PALETTE * sizeof(par_color))) != hipSuccess) return bail(e);
@@ -319,7 +333,7 @@ int par_create(const par_params* params, int device, par_context** out) {
     if ((e = hipMalloc(&ctx->d_dyn, sizeof(par_frame_dyn))) != hipSuccess) return bail(e);
     if ((e = hipMemcpy(ctx->d_palette, p.palette, PAR_MAX_PALETTE * sizeof(par_color), hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if ((e = hipMemset(ctx->grid.slots, 0, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return bail(e);
     }
     if (reset_grid(ctx) != PAR_OK) {
@@ -343,7 +357,10 @@ void par_destroy(par_context* ctx) {
     for (int s = 0; s < 2; s++) {
         if (ctx->grid.head[s]) (void)hipFree(ctx->grid.head[s]);
         if (ctx->grid.count[s]) (void)hipFree(ctx->grid.count[s]);
+        if (ctx->grid.colflag[s]) (void)hipFree(ctx->grid.colflag[s]);
     }
+    if (ctx->grid.col_list) (void)hipFree(ctx->grid.col_list);
+    if (ctx->grid.ncols) (void)hipFree(ctx->grid.ncols);
     void* ptrs[] = {ctx->grid.slots, ctx->grid.node_counter, ctx->d_palette, ctx->d_ray_counter, ctx->d_dyn,
                     ctx->d_aabbs, ctx->d_sprite_ids, ctx->d_sprites};
     for (void* p : ptrs) {
@@ -354,7 +371,7 @@ void par_destroy(par_context* ctx) {
     }
     if (ctx->pin_aabbs) (void)hipHostFree(ctx->pin_aabbs);
     if (ctx->pin_dyn) (void)hipHostFree(ctx->pin_dyn);
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < 4; i++) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -526,7 +543,8 @@ int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int r
     ctx->last_flags = flags;
     PAR_HIP(hipEventSynchronize(ctx->ev[2]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_bin, ctx->ev[0], ctx->ev[1]));
-    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[1], ctx->ev[2]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_fill, ctx->ev[1], ctx->ev[3]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[3], ctx->ev[2]));
     if (stats) return par_get_stats(ctx, stats);
     return PAR_OK;
 }

@@ -17,14 +17,14 @@ struct par_slot {
 };
 static_assert(sizeof(par_slot) == 16, "slot record must stay 16 bytes");
 
-// Kernel geometry (see DESIGN.md "render kernel").
-constexpr int PAR_NT = 320;          // threads per workgroup = 5 wavefronts
-constexpr int PAR_KPT = 5;           // pixels per thread -> up to 1600 pixels (one 40x40 bin footprint) per workgroup
-constexpr int PAR_TILE_PIXELS = PAR_NT * PAR_KPT;
+// Kernel geometry (see DESIGN.md "kernels").
+constexpr int PAR_NT = 320;             // threads per render workgroup = 5 wavefronts, one pixel per thread
 constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count the LDS column list is sized for
-constexpr int PAR_MAX_ENTRIES = 512;    // column slot records staged in LDS (the rest is read from HBM/L2)
-constexpr int PAR_MAX_OCC = 1024;       // shadow-occluder records staged in LDS per round
-constexpr int PAR_CHAIN_ITERS = PAR_NT / 8;  // walk iterations per probe chunk (8 lanes per iteration, 7 used)
+constexpr int PAR_MAX_ENTRIES = 256;    // column slot records staged in LDS (the rest is read from L2/HBM)
+constexpr int PAR_MAX_OCC = 512;        // shadow-occluder records staged in LDS per round
+constexpr int PAR_CHAIN_MAX = 1024;     // walk iterations whose bin coordinates are staged in LDS at a time
+constexpr int PAR_PPT = 3;              // shadow-walk probes per thread per batch
+constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = PAR_NT;  // bin sizes the tile mapping supports
 
 // Per-frame values that change without the scene being re-uploaded. In the hipGraph path they live in device memory
 // (updated by a memcpy node); otherwise they travel as kernel arguments.
@@ -37,21 +37,33 @@ struct par_grid_dev {
     int32_t gx, gy, gz, volume;
     int32_t* head[2];         // [volume] node index + 1 of the most recent insertion, 0 = none
     uint8_t* count[2];        // [volume] visible count = insertions & 7 (alt:262-264)
+    int32_t* colflag[2];      // [gx*gy] 1 when some bin of screen column (bx, by) shows entries this frame
     par_slot* slots;          // [volume * 8]
     int32_t* node_entity[2];  // [capacity]
     int32_t* node_next[2];    // [capacity]
     int32_t* node_bin[2];     // [capacity]
     int32_t* node_counter;    // [2]
+    int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
+    int32_t* ncols;           // [1]
     int32_t capacity;
+};
+
+struct par_bin_args {
+    int32_t W, H, L, B;
+    int32_t n;
+    int32_t set;             // which head/count/node/colflag set this frame uses
+    int32_t by_lo, by_hi;    // bin rows [by_lo, by_hi] the render of this frame touches (column-list filter)
+    const par_aabb* aabbs;
 };
 
 struct par_render_args {
     int32_t W, H, B;
     int32_t row_begin, row_end;    // rows rendered by this launch
-    int32_t by_begin;              // first bin row touched
-    int32_t tile_rows;             // rows per workgroup tile (R)
-    int32_t subs;                  // tiles per bin row = ceil(B / R)
-    uint32_t magic_b;              // floor(p / B) == __umulhi(p, magic_b) for p < PAR_TILE_PIXELS
+    int32_t by_lo, by_hi;          // bin rows touched
+    int32_t tile_rows;             // rows per workgroup tile: PAR_NT / B
+    int32_t subs;                  // tiles per bin row = ceil(B / tile_rows)
+    int32_t dense;                 // 1: every column is rendered by render_tiles (every ray traced), no fill pass
+    uint32_t magic_b;              // floor(n / B) == __umulhi(n, magic_b) for n * B < 2^32
     float ambient;
     uint32_t background;           // gray level (alt:281)
     uint32_t flags;
@@ -59,6 +71,7 @@ struct par_render_args {
     par_frame_dyn dyn;             // used when dyn_ptr == nullptr
     const par_frame_dyn* dyn_ptr;  // graph path
     const uint8_t* count;
+    const int32_t* colflag;
     const par_slot* slots;
     const par_sprite* sprites;
     const int32_t* sprite_ids;     // nullable
@@ -67,16 +80,12 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
-struct par_bin_args {
-    int32_t W, H, L, B;
-    int32_t n;
-    int32_t set;  // which head/count/node set this frame uses
-    const par_aabb* aabbs;
-};
-
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
-hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
+// Background for the columns no primitive shows in (skipped when a.dense).
+hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
+// `column_bound`: an upper bound of the occupied columns in the row range (ignored when a.dense).
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
 
 #endif

@@ -19,9 +19,16 @@ def run(name, params, aabbs, light, flags=0, planes=("fb", "palidx"), n=30):
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(5):
         r.render_device(ptrs, stream=s, flags=flags, timed=True)
-    ms = [r.render_device(ptrs, stream=s, flags=flags, timed=True).ms_render for _ in range(n)]
-    mb = [r.render_device(ptrs, stream=s, flags=flags, timed=True).ms_bin for _ in range(5)]
-    print(f"{name:50s} render {np.mean(ms)*1e3:9.1f} us (min {np.min(ms)*1e3:8.1f})  bin {np.mean(mb)*1e3:7.1f} us  pairs {r.stats().bin_insertions}")
+    st = [r.render_device(ptrs, stream=s, flags=flags, timed=True) for _ in range(n)]
+    ms = [x.ms_render for x in st]; mf = [x.ms_fill for x in st]; mb = [x.ms_bin for x in st]
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(100):
+        r.render_device(ptrs, stream=s, flags=flags)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 100
+    print(f"{name:44s} render {np.mean(ms)*1e3:8.1f} (min {np.min(ms)*1e3:7.1f})  fill {np.mean(mf)*1e3:6.1f}  bin {np.mean(mb)*1e3:6.1f} us  frame(wall) {wall*1e6:7.1f} us  pairs {r.stats().bin_insertions}")
     r.close()
 
 W = H = L = 4096
