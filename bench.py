@@ -187,29 +187,50 @@ def main():
     # ---- roofline of the dominant kernel + the all-rays-traced rate (N = 1 only; untimed extras) -------------
     if world == 1:
         ptrs = {"fb": fb[0].data_ptr(), "palidx": pal[0].data_ptr()}
-        ms_render, ms_bin = [], []
+        ms = {"bin": [], "fill": [], "render": []}
         for _ in range(5):
             r.render_device(ptrs, stream=stream, timed=True)
         for _ in range(30):
             st = r.render_device(ptrs, stream=stream, timed=True)
-            ms_render.append(st.ms_render)
-            ms_bin.append(st.ms_bin)
-        avg_render = float(np.mean(ms_render))
-        # algorithmic bytes per launch: 2.5 B per nominal ray (4 B RGBA + 1 B palette index per pixel,
-        # two rays per pixel) x 2*W*H rays
-        algo_bytes = 2.5 * 2.0 * W * H
-        achieved = algo_bytes / (avg_render * 1e-3) / 1e9
+            ms["bin"].append(st.ms_bin)
+            ms["fill"].append(st.ms_fill)
+            ms["render"].append(st.ms_render)
+        avg = {k: float(np.mean(v)) for k, v in ms.items()}
+        ncols = int(r.stats().occupied_columns)
+        gx, gy, gz = params.grid_dims()
+        # Algorithmic bytes: 2.5 B per nominal ray (4 B RGBA + 1 B palette index per pixel, two rays per
+        # pixel). The frame's pixels are written by two kernels: render_tiles_kernel owns the pixels of the screen
+        # columns that show a primitive (one column = one 40x40 bin footprint), fill_kernel the rest.
+        B_ = params.bin_size
+        px_render = min(int(ncols) * B_ * B_, W * H)  # edge columns are narrower: a slight over-count
+        bytes_frame = 2.5 * 2.0 * W * H
+        bytes_render = 5.0 * px_render
+        bytes_fill = bytes_frame - bytes_render
+        dominant = "render_tiles_kernel" if avg["render"] >= avg["fill"] else "fill_kernel"
+        dom_bytes = bytes_render if dominant == "render_tiles_kernel" else bytes_fill
+        dom_ms = avg["render"] if dominant == "render_tiles_kernel" else avg["fill"]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get("render_kernel_hbm_bytes_per_launch")
+                traffic = json.load(f).get(dominant + "_hbm_bytes_per_launch")
+        frame_ms = avg["bin"] + avg["fill"] + avg["render"]
         out["roofline"] = {
-            "kernel": "render_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+            "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": int(algo_bytes), "avg_kernel_ms": round(avg_render, 5),
-            "avg_bin_kernels_ms": round(float(np.mean(ms_bin)), 5),
+            "algorithmic_bytes_per_launch": int(dom_bytes), "avg_kernel_ms": round(dom_ms, 5),
             "timing": "hipEvent pairs around the kernel on its launch stream, mean of 30 frames",
+            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); this kernel writes "
+                        f"{px_render if dominant == 'render_tiles_kernel' else W * H - px_render} of {W * H} pixels",
+            "kernels_ms": {"hash_build_and_walk": round(avg["bin"], 5), "fill_kernel": round(avg["fill"], 5),
+                           "render_tiles_kernel": round(avg["render"], 5)},
+            "fill_kernel": {"achieved": round(bytes_fill / (avg["fill"] * 1e-3) / 1e9, 1),
+                            "frac": round(bytes_fill / (avg["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "whole_frame": {"achieved": round(bytes_frame / (frame_ms * 1e-3) / 1e9, 1),
+                            "frac": round(bytes_frame / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "device_ms": round(frame_ms, 5)},
+            "occupied_columns": ncols, "columns": gx * gy,
         }
         # every ray traced, as the reference does (PAR_RENDER_TRACE_BACKGROUND)
         for i in range(3):

@@ -32,6 +32,7 @@ struct par_context {
     int32_t* d_sprite_ids = nullptr;
     par_sprite* d_sprites = nullptr;
     par_color* d_palette = nullptr;
+    par_texel* d_texinfo = nullptr;
     unsigned long long* d_ray_counter = nullptr;
     par_grid_dev grid{};
     int aabb_capacity = 0;
@@ -102,6 +103,10 @@ void free_pool(par_context* c) {
         if (c->grid.node_bin[s]) (void)hipFree(c->grid.node_bin[s]);
         c->grid.node_entity[s] = c->grid.node_next[s] = c->grid.node_bin[s] = nullptr;
     }
+    if (c->grid.walk_cnt) (void)hipFree(c->grid.walk_cnt);
+    if (c->grid.walk_rec) (void)hipFree(c->grid.walk_rec);
+    c->grid.walk_cnt = nullptr;
+    c->grid.walk_rec = nullptr;
     c->grid.capacity = 0;
 }
 
@@ -132,6 +137,8 @@ int ensure_pool(par_context* ctx, int64_t pairs) {
         PAR_HIP(hipMalloc(&ctx->grid.node_next[s], (size_t)cap * sizeof(int32_t)));
         PAR_HIP(hipMalloc(&ctx->grid.node_bin[s], (size_t)cap * sizeof(int32_t)));
     }
+    PAR_HIP(hipMalloc(&ctx->grid.walk_cnt, (size_t)cap * sizeof(int32_t)));
+    PAR_HIP(hipMalloc(&ctx->grid.walk_rec, (size_t)cap * PAR_WALK_CAP * sizeof(par_slot)));
     ctx->grid.capacity = (int32_t)cap;
     return reset_grid(ctx);
 }
@@ -193,6 +200,8 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.colflag = c->grid.colflag[set];
     a.slots = c->grid.slots;
     a.sprites = c->d_sprites;
+    a.texinfo = c->d_texinfo;
+    a.head = c->grid.head[set];
     a.sprite_ids = c->d_sprite_ids;
     a.palette = c->d_palette;
     a.out = out;
@@ -223,6 +232,13 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
     // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
     PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
+    {
+        par_walk_args w{};
+        w.set = set;
+        w.dyn = r.dyn;
+        w.dyn_ptr = r.dyn_ptr;
+        PAR_HIP(par_launch_walk(ctx->grid, w, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
+    }
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
     PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
@@ -362,7 +378,7 @@ void par_destroy(par_context* ctx) {
     if (ctx->grid.col_list) (void)hipFree(ctx->grid.col_list);
     if (ctx->grid.ncols) (void)hipFree(ctx->grid.ncols);
     void* ptrs[] = {ctx->grid.slots, ctx->grid.node_counter, ctx->d_palette, ctx->d_ray_counter, ctx->d_dyn,
-                    ctx->d_aabbs, ctx->d_sprite_ids, ctx->d_sprites};
+                    ctx->d_aabbs, ctx->d_sprite_ids, ctx->d_sprites, ctx->d_texinfo};
     for (void* p : ptrs) {
         if (p) (void)hipFree(p);
     }
@@ -395,6 +411,20 @@ int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) 
     ctx->n_sprites = 0;
     PAR_HIP(hipMalloc(&ctx->d_sprites, (size_t)n_sprites * sizeof(par_sprite)));
     PAR_HIP(hipMemcpy(ctx->d_sprites, sprites, (size_t)n_sprites * sizeof(par_sprite), hipMemcpyHostToDevice));
+    // per-texel shading record: normal + the palette colour its index resolves to (alt:349-354)
+    std::vector<par_texel> tex((size_t)n_sprites * PAR_SPRITE_TEXELS);
+    for (int s = 0; s < n_sprites; s++) {
+        for (int t = 0; t < PAR_SPRITE_TEXELS; t++) {
+            const par_color pc = ctx->params.palette[sprites[s].color[t]];
+            par_texel& x = tex[(size_t)s * PAR_SPRITE_TEXELS + t];
+            x.nx = sprites[s].normal[t].x; x.ny = sprites[s].normal[t].y; x.nz = sprites[s].normal[t].z;
+            x.rgba = (uint32_t)pc.red | ((uint32_t)pc.green << 8) | ((uint32_t)pc.blue << 16) | ((uint32_t)pc.alpha << 24);
+        }
+    }
+    if (ctx->d_texinfo) PAR_HIP(hipFree(ctx->d_texinfo));
+    ctx->d_texinfo = nullptr;
+    PAR_HIP(hipMalloc(&ctx->d_texinfo, tex.size() * sizeof(par_texel)));
+    PAR_HIP(hipMemcpy(ctx->d_texinfo, tex.data(), tex.size() * sizeof(par_texel), hipMemcpyHostToDevice));
     ctx->n_sprites = n_sprites;
     return PAR_OK;
 }
@@ -639,6 +669,11 @@ int par_get_stats(par_context* ctx, par_frame_stats* stats) {
     ctx->stats.entities = ctx->n_entities;
     ctx->stats.bin_insertions = ctx->total_pairs;
     ctx->stats.shadow_rays = -1;
+    {
+        int32_t nc = 0;
+        PAR_HIP(hipMemcpy(&nc, ctx->grid.ncols, sizeof(nc), hipMemcpyDeviceToHost));
+        ctx->stats.occupied_columns = nc;
+    }
     if (ctx->last_flags & PAR_RENDER_COUNT_RAYS) {
         unsigned long long v = 0;
         PAR_HIP(hipMemcpy(&v, ctx->d_ray_counter, sizeof(v), hipMemcpyDeviceToHost));

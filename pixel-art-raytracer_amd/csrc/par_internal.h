@@ -24,7 +24,17 @@ constexpr int PAR_MAX_ENTRIES = 256;    // column slot records staged in LDS (th
 constexpr int PAR_MAX_OCC = 512;        // shadow-occluder records staged in LDS per round
 constexpr int PAR_CHAIN_MAX = 1024;     // walk iterations whose bin coordinates are staged in LDS at a time
 constexpr int PAR_PPT = 3;              // shadow-walk probes per thread per batch
+constexpr int PAR_WALK_CAP = 32;        // occluder records precomputed per start bin (longer lists: in-kernel walk)
 constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = PAR_NT;  // bin sizes the tile mapping supports
+
+// What the shading pass needs of a sprite texel besides its depth, in one 16-byte record: the normal (spr:70) and
+// the palette colour the texel's index resolves to (spr:68 through color_palette, alt:352-354). Built on the host
+// when sprites are uploaded; one load instead of three dependent ones.
+struct par_texel {
+    float nx, ny, nz;
+    uint32_t rgba;
+};
+static_assert(sizeof(par_texel) == 16, "texel record must stay 16 bytes");
 
 // Per-frame values that change without the scene being re-uploaded. In the hipGraph path they live in device memory
 // (updated by a memcpy node); otherwise they travel as kernel arguments.
@@ -45,6 +55,9 @@ struct par_grid_dev {
     int32_t* node_counter;    // [2]
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
     int32_t* ncols;           // [1]
+    int32_t* walk_cnt;        // [capacity] per head node: occluder records found by the shadow walk from its bin,
+                              //            or -1 when the list did not fit (the render kernel then walks itself)
+    par_slot* walk_rec;       // [capacity * PAR_WALK_CAP]
     int32_t capacity;
 };
 
@@ -74,15 +87,25 @@ struct par_render_args {
     const int32_t* colflag;
     const par_slot* slots;
     const par_sprite* sprites;
+    const par_texel* texinfo;      // [n_sprites * 800]
+    const int32_t* head;           // this frame's list heads (start bin -> head node -> precomputed walk)
     const int32_t* sprite_ids;     // nullable
     const par_color* palette;
     par_outputs out;               // device pointers, addressing (row_begin, 0)
     unsigned long long* ray_counter;
 };
 
+struct par_walk_args {
+    int32_t set;
+    par_frame_dyn dyn;
+    const par_frame_dyn* dyn_ptr;
+};
+
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
+// Shadow walk from every occupied bin -> per-bin occluder lists (walk_cnt / walk_rec).
+hipError_t par_launch_walk(const par_grid_dev& g, const par_walk_args& a, int64_t pair_bound, hipStream_t stream);
 // Background for the columns no primitive shows in (skipped when a.dense).
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
 // `column_bound`: an upper bound of the occupied columns in the row range (ignored when a.dense).

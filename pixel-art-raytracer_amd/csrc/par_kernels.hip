@@ -21,6 +21,15 @@ __device__ __forceinline__ int flat_index(int gy, int gz, int x, int y, int z) {
     return x * gy * gz + y * gz + z;  // index_into_view_hash alt:180-182
 }
 
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(v, d);
+        if (lane >= d) v += y;
+    }
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // Spatial hash build.
 //
@@ -33,6 +42,11 @@ __device__ __forceinline__ int flat_index(int gy, int gz, int x, int y, int z) {
 // touched in the other set, so no O(volume) memset is ever issued after context creation.
 // ------------------------------------------------------------------------------------------------------------
 
+// ENT entities per wavefront (16 for small scenes so that the pairs of one wavefront fit one or two passes, 64 for
+// large ones so that the node counter sees one atomic per 64 entities). Lane l < ENT culls and sizes entity l; the
+// wavefront reserves its nodes with ONE atomic; then all 64 lanes walk the (entity, bin) pairs side by side, so the
+// list-head exchanges of a wavefront are in flight together instead of one after the other.
+template <int ENT>
 __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin_args a) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     const int stride = gridDim.x * blockDim.x;
@@ -48,38 +62,62 @@ __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin
     }
     if (tid == 0) *g.ncols = 0;
 
-    // 16 lanes per entity: one lane per bin of its box (most boxes span <= 12 bins), so the atomics of one entity
-    // are issued side by side instead of one after the other.
     const int W = a.W, H = a.H, L = a.L, B = a.B;
-    const int sub = tid & 15;
-    for (int e = tid >> 4; e < a.n; e += stride >> 4) {
-        const par_aabb box = a.aabbs[e];
-        const int minx = box.px, miny = box.py, minz = box.pz;                       // alt:202-204
-        const int maxx = minx + box.ex, maxy = miny + box.ey, maxz = minz + box.ez;  // alt:206-208
-        int nx = 0, ny = 0, nz = 0, x0 = 0, y0 = 0, z0 = 0;
-        const bool culled = (maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) ||
-                            (maxz < -box.ez - B) || (minz > L + B);          // alt:212-219
-        if (!culled) {
-            x0 = max(0, minx / B);                                           // alt:222
-            y0 = max(0, (H - maxy - maxz) / B);                              // alt:223-225
-            z0 = max(0, minz / B);                                           // alt:226
-            nx = max(0, min(g.gx, (maxx + B - 1) / B) - x0);                 // alt:228-230
-            ny = max(0, min(g.gy, (H - miny - minz + B - 1) / B) - y0);      // alt:231-236
-            nz = max(0, min(g.gz, (maxz + B - 1) / B) - z0);                 // alt:238-240
+    const int lane = threadIdx.x & 63;
+    const int n_waves = stride >> 6;
+    for (int e0 = (tid >> 6) * ENT; e0 < a.n; e0 += n_waves * ENT) {  // wave-uniform loop
+        const int e = e0 + lane;
+        int k = 0, org = 0, dim = 0;
+        if (lane < ENT && e < a.n) {
+            const par_aabb box = a.aabbs[e];
+            const int minx = box.px, miny = box.py, minz = box.pz;                       // alt:202-204
+            const int maxx = minx + box.ex, maxy = miny + box.ey, maxz = minz + box.ez;  // alt:206-208
+            const bool culled = (maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) ||
+                                (maxz < -box.ez - B) || (minz > L + B);  // alt:212-219
+            if (!culled) {
+                const int x0 = max(0, minx / B);                                       // alt:222
+                const int y0 = max(0, (H - maxy - maxz) / B);                          // alt:223-225
+                const int z0 = max(0, minz / B);                                       // alt:226
+                const int nx = max(0, min(g.gx, (maxx + B - 1) / B) - x0);             // alt:228-230
+                const int ny = max(0, min(g.gy, (H - miny - minz + B - 1) / B) - y0);  // alt:231-236
+                const int nz = max(0, min(g.gz, (maxz + B - 1) / B) - z0);             // alt:238-240
+                k = nx * ny * nz;
+                org = x0 | (y0 << 10) | (z0 << 20);  // grid dimensions are at most 1024 per axis
+                dim = ny | (nz << 11);               // box spans are at most 1024 bins per axis
+            }
         }
-        const int k = nx * ny * nz;
+        const int incl = wave_incl_scan_i(k, lane);
+        const int excl = incl - k;
+        const int total = __shfl(incl, 63);
+        if (total == 0) continue;
         int base = 0;
-        if (sub == 0 && k > 0) base = atomicAdd(&g.node_counter[s], k);
-        base = __shfl(base, 0, 16);
-        for (int j = sub; j < k; j += 16) {
-            const int jz = j % nz, t = j / nz;
-            const int jy = t % ny, jx = t / ny;
-            const int b = flat_index(g.gy, g.gz, x0 + jx, y0 + jy, z0 + jz);
-            const int node = base + j;
-            if (node < g.capacity) {  // the host sizes the pool from the exact pair count; belt and braces
-                g.node_entity[s][node] = e;
-                g.node_bin[s][node] = b;
-                g.node_next[s][node] = atomicExch(&g.head[s][b], node + 1);
+        if (lane == 0) base = atomicAdd(&g.node_counter[s], total);
+        base = __shfl(base, 0);
+        for (int p0 = 0; p0 < total; p0 += 64) {  // wave-uniform: every lane takes part in the shuffles below
+            const int p = p0 + lane;
+            // owner of pair p: the last lane whose exclusive offset is <= p (lanes with k == 0 share their
+            // successor's offset and are skipped by taking the last)
+            int lo = 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int cand = lo + d;
+                const int v = __shfl(excl, cand & 63);
+                if (cand < 64 && v <= p) lo = cand;
+            }
+            const int j = p - __shfl(excl, lo);
+            const int o3 = __shfl(org, lo), d3 = __shfl(dim, lo);
+            if (p < total) {
+                const int ny = d3 & 0x7FF, nz = d3 >> 11;
+                const int jz = j % nz, t = j / nz;
+                const int jy = t % ny, jx = t / ny;
+                const int b = flat_index(g.gy, g.gz, (o3 & 0x3FF) + jx, ((o3 >> 10) & 0x3FF) + jy, (o3 >> 20) + jz);
+                const int node = base + p;
+                // the host sizes the pool from the exact pair count and b is in range by construction: belt and braces
+                if (node < g.capacity && b >= 0 && b < g.volume) {
+                    g.node_entity[s][node] = e0 + lo;
+                    g.node_bin[s][node] = b;
+                    g.node_next[s][node] = atomicExch(&g.head[s][b], node + 1);
+                }
             }
         }
     }
@@ -140,14 +178,7 @@ __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bi
 // Small device helpers
 // ------------------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int y = __shfl_up(v, d);
-        if (lane >= d) v += y;
-    }
-    return v;
-}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) { return wave_incl_scan_i(v, lane); }
 
 // Exclusive prefix sum over the workgroup; two barriers. `total` is uniform.
 __device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum, int& total) {
@@ -221,6 +252,104 @@ __device__ __forceinline__ int div_bin(int n, uint32_t magic) {
 __device__ __forceinline__ int xcd_remap(int b, int nb) {
     const int q = nb >> 3, rem = nb & 7, xcd = b & 7;
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// walk_kernel: the bin sequence trace_hash_for_light (alt:399-500) probes depends only on the start bin and the
+// light's bin, not on the ray. Shadow rays start in bins that hold primitives, so one wavefront per occupied bin
+// walks from it to the light ONCE per frame and records the slot records of every occupied bin on the way (the
+// start bin excluded, alt:471-473). A pixel whose ray starts there then only slab-tests that short list. The
+// reference's result is an OR over the probes, so neither probe order nor duplicates matter. Lists longer than
+// PAR_WALK_CAP are marked -1; the render kernel walks those itself.
+// ------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void walk_kernel(par_grid_dev g, par_walk_args a) {
+    __shared__ int16_t chain_all[4][3][65];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int16_t(*chain)[65] = chain_all[wave];
+    const int s = a.set;
+    const int node = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
+    if (node >= min(g.node_counter[s], g.capacity)) return;
+    const int b0 = g.node_bin[s][node];
+    if (g.head[s][b0] != node + 1) return;  // one walk per bin: the list head's
+    const uint8_t* count = g.count[s];
+    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+
+    const int sx = b0 / (g.gy * g.gz);
+    const int rem = b0 - sx * g.gy * g.gz;
+    const int sy = rem / g.gz, sz = rem - (rem / g.gz) * g.gz;
+    // alt:406-430
+    const float fsx = (float)sx, fsy = (float)sy, fsz = (float)sz;
+    const float ddx = (float)dyn.lbx - fsx, ddy = (float)dyn.lby - fsy, ddz = (float)dyn.lbz - fsz;
+    float largest = __builtin_fabsf(ddx);
+    if (largest < __builtin_fabsf(ddy)) largest = __builtin_fabsf(ddy);
+    if (largest < __builtin_fabsf(ddz)) largest = __builtin_fabsf(ddz);
+    const int m = (int)largest;  // alt:432
+    const float step_mine = ((lane == 0) ? ddx : ((lane == 1) ? ddy : ddz)) / largest;  // alt:423-425
+    float carry = (lane == 0) ? fsx : ((lane == 1) ? fsy : fsz);
+    par_slot* out = g.walk_rec + (size_t)node * PAR_WALK_CAP;
+    int total = 0;
+    bool overflow = false;
+
+    for (int it0 = 0; it0 < m; it0 += 64) {
+        const int n_it = min(64, m - it0);
+        if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
+            float v = carry;
+            chain[lane][0] = (int16_t)(int)v;  // alt:468
+            for (int i = 1; i <= n_it; i++) {
+                v = v + step_mine;
+                chain[lane][i] = (int16_t)(int)v;
+            }
+            carry = v;
+        }
+        // same wavefront wrote and reads: LDS operations of one wavefront complete in order; keep the compiler
+        // from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        int idx[7], cnt[7];
+        int mine = 0;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            idx[q] = 0;
+            cnt[q] = 0;
+        }
+        if (lane < n_it) {
+            const int ax = chain[0][lane], ay = chain[1][lane], az = chain[2][lane];
+            const int qx = chain[0][lane + 1], qy = chain[1][lane + 1], qz = chain[2][lane + 1];
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                const int mask = q + 1;
+                const bool canonical = (!(mask & 1) || qx != ax) && (!(mask & 2) || qy != ay) &&
+                                       (!(mask & 4) || qz != az);
+                if (canonical) {
+                    const int b = flat_index(g.gy, g.gz, (mask & 1) ? qx : ax, (mask & 2) ? qy : ay,
+                                             (mask & 4) ? qz : az);
+                    if (b != b0 && b >= 0 && b < g.volume) {  // alt:471-473; out of range reads as empty (alt:476)
+                        idx[q] = b;
+                        cnt[q] = count[b];
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 7; q++) mine += cnt[q];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int incl = wave_incl_scan_i(mine, lane);
+        const int wave_total = __shfl(incl, 63);
+        if (total + wave_total > PAR_WALK_CAP) {
+            overflow = true;
+            break;
+        }
+        int o = total + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            for (int k = 0; k < cnt[q]; k++) out[o++] = g.slots[(size_t)idx[q] * PAR_SLOTS + k];
+        }
+        total += wave_total;
+    }
+    if (lane == 0) g.walk_cnt[node] = overflow ? -1 : total;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -316,8 +445,10 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
         by = a.by_lo + ci / g.gx;  // x fastest: neighbours in x share lines of the frame
         bx = ci - (ci / g.gx) * g.gx;
     } else {
-        if (ci >= *g.ncols) return;  // the launch is sized by an upper bound of the occupied columns
+        // the launch is sized by an upper bound of the occupied columns; both loads are issued together
+        const int n_cols = *g.ncols;
         const int col = g.col_list[ci];
+        if (ci >= n_cols) return;
         bx = col / g.gy;
         by = col - bx * g.gy;
     }
@@ -344,10 +475,17 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
     for (int t = tid; t < PAR_SPRITE_TEXELS; t += PAR_NT) sm.sprite_depth[t] = a.sprites[0].depth[t];
 
     // ---- phase 1: the column (bx, by, *) -> ordered list of non-empty bins and their slot records in LDS -----
+    // Lane t reads the count of bin_z = t and, without waiting for it, the bin's first slot record: most occupied
+    // bins hold a single primitive, so the record is already there when the count arrives.
+    // While copying, each lane also checks whether its records can cover any pixel of THIS tile.
+    const int wj_hi = H - r0, wj_lo = H - r1 + 1;  // world_j range of the tile's rows (alt:280)
     int nb_base = 0, ent_base = 0;
+    int covers = 0;
     for (int t0 = 0; t0 < g.gz; t0 += PAR_NT) {
         const int t = t0 + tid;
+        const par_slot* src = a.slots + (size_t)(col_base + min(t, g.gz - 1)) * PAR_SLOTS;
         const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;  // consecutive bytes: coalesced
+        const par_slot first = src[0];
         int total;
         const int packed = block_excl_scan(((c != 0) << 16) | c, sm.wsum, total);
         const int nb_i = nb_base + (packed >> 16);
@@ -356,22 +494,45 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
             sm.nb_bz[nb_i] = (int16_t)t;
             sm.nb_off[nb_i] = (int16_t)off;
             sm.nb_cnt[nb_i] = (uint8_t)c;
-            const par_slot* src = a.slots + (size_t)(col_base + t) * PAR_SLOTS;
             for (int k = 0; k < c; k++) {
-                if (off + k < PAR_MAX_ENTRIES) sm.entries[off + k] = src[k];
+                const par_slot rec = (k == 0) ? first : src[k];
+                if (off + k < PAR_MAX_ENTRIES) sm.entries[off + k] = rec;
+                // alt:310-317 over the tile's pixel rectangle
+                covers |= (rec.px < c0 + tw) && (rec.px + rec.ex > c0) && (wj_hi > rec.py + rec.pz) &&
+                          (wj_lo <= rec.py + rec.ey + rec.pz + rec.ez);
             }
         }
         nb_base += total >> 16;
         ent_base += total & 0xFFFF;
     }
-    __syncthreads();
     const int n_nb = nb_base;
+    // barrier for the LDS lists; it also tells whether any record can cover a pixel of this tile
+    const int any_cover = __syncthreads_or(covers);
 
     // ---- this lane's pixel ----------------------------------------------------------------------------------
     const int py = (int)__umulhi((uint32_t)tid, a.magic_b);
     const int px = tid - py * B;
     const int col = c0 + px, row = tile_r0 + py;
     const bool valid = (px < tw) && (row >= r0) && (row < r1);
+    const size_t o = (size_t)(row - a.row_begin) * W + col;
+
+    if (!any_cover && !trace_bg) {
+        // nothing in this column reaches this tile: background (alt:281 -> alt:735), and no shadow ray to skip
+        if (valid) {
+            if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(bg_rgba, ambient);
+            if (a.out.palidx) a.out.palidx[o] = PAR_PALIDX_BACKGROUND;
+            if (a.out.brightness) a.out.brightness[o] = ambient;
+            if (a.out.gbuf) {
+                par_pixel bgp;
+                bgp.normal = par_vec3{0.f, 0.f, 0.f};
+                bgp.color.red = bgp.color.green = bgp.color.blue = (uint8_t)a.background;
+                bgp.color.alpha = 0;
+                bgp.y = 0; bgp.z = 0; bgp.entity_index = 0;
+                a.out.gbuf[o] = bgp;
+            }
+        }
+        return;
+    }
 
     // ---- phase 2: primary ray, alt:271-397 -----------------------------------------------------------------
     bool hit = false;
@@ -431,14 +592,13 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
     uint32_t rgba = bg_rgba;
     int pal_index = PAR_PALIDX_BACKGROUND;
     if (hit) {
-        const int sid = p_tex / PAR_SPRITE_TEXELS;
-        const int t = p_tex - sid * PAR_SPRITE_TEXELS;
-        const par_vec3 n = a.sprites[sid].normal[t];  // alt:349-350
-        nx = n.x; ny = n.y; nz = n.z;
-        pal_index = a.sprites[sid].color[t];
-        const par_color pc = a.palette[pal_index];    // alt:352-354
-        rgba = (uint32_t)pc.red | ((uint32_t)pc.green << 8) | ((uint32_t)pc.blue << 16) |
-               ((uint32_t)pc.alpha << 24);
+        const par_texel ti = a.texinfo[p_tex];  // normal (alt:349-350) + resolved palette colour (alt:352-354)
+        nx = ti.nx; ny = ti.ny; nz = ti.nz;
+        rgba = ti.rgba;
+        if (a.out.palidx) {
+            const int sid = p_tex / PAR_SPRITE_TEXELS;
+            pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
+        }
     } else {
         p_entity = 0; p_y = 0; p_z = 0;
     }
@@ -470,7 +630,28 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
     }
     const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
 
-    // ---- phase 4: shadow rays, alt:738-742 + alt:399-500 ---------------------------------------------------
+    // ---- phase 4a: the precomputed walk of the pixel's start bin (walk_kernel) -------------------------------
+    if (pend && !(a.flags & (1u << 28))) {  // bit 28: ablation, force the in-kernel walk
+        const int sy0 = ((key >> 16) & 0x7FFF) - 16384, sz0 = (key & 0xFFFF) - 32768;
+        const int sidx = flat_index(g.gy, g.gz, bx, sy0, sz0);
+        const int node = (sidx >= 0 && sidx < g.volume) ? a.head[sidx] - 1 : -1;
+        const int n_rec = (node >= 0) ? g.walk_cnt[node] : -1;
+        if (n_rec >= 0) {
+            const par_slot* recs = g.walk_rec + (size_t)node * PAR_WALK_CAP;
+            for (int r = 0; r < n_rec; r++) {
+                const par_slot rec = recs[r];
+                if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
+                    lit = false;
+                    break;
+                }
+            }
+            pend = false;  // resolved; pixels left pending take the in-kernel walk below
+        }
+    }
+
+    // ---- phase 4b: in-kernel shadow walk, alt:738-742 + alt:399-500 ----------------------------------------
+    // For pixels without a precomputed list (start bin holds no primitive: background rays when every ray is
+    // traced, negative world z, exotic sprite depths; or the list overflowed).
     // Pixels of the tile whose walk starts in the same bin visit the same bins (the probe sequence depends only on
     // the start and light bins), so the walk is done once per distinct start bin by the whole workgroup; the
     // occupied bins it finds are staged in LDS and every pixel of the group slab-tests that list. The result of
@@ -589,7 +770,6 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
     // ---- phase 5: quantise + store, alt:735, 757-758 --------------------------------------------------------
     if (!valid) return;
     const float bright = lit ? b_lit : ambient;
-    const size_t o = (size_t)(row - a.row_begin) * W + col;
     if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
     if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
     if (a.out.brightness) a.out.brightness[o] = bright;
@@ -611,13 +791,18 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
 }  // namespace
 
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream) {
-    // 16 lanes per entity; the wipe of the previous frame's nodes is a grid-stride loop over at most `capacity`
-    int64_t work = (int64_t)a.n * 16;
+    // ENT entities per wavefront; the wipe of the previous frame's nodes is a grid-stride loop over <= capacity
+    const bool small = a.n <= 16384;
+    int64_t work = (int64_t)a.n * (small ? 4 : 1);  // threads = waves * 64 = n / ENT * 64
     if (work < g.capacity) work = g.capacity;
     int64_t blocks = (work + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(bin_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    if (small) {
+        hipLaunchKernelGGL(bin_insert_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    } else {
+        hipLaunchKernelGGL(bin_insert_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    }
     return hipGetLastError();
 }
 
@@ -626,6 +811,13 @@ hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, 
     int64_t blocks = (pair_bound + 255) / 256;
     if (blocks < 1) blocks = 1;  // block 0 always runs: it resets the other set's node counter
     hipLaunchKernelGGL(bin_resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    return hipGetLastError();
+}
+
+hipError_t par_launch_walk(const par_grid_dev& g, const par_walk_args& a, int64_t pair_bound, hipStream_t stream) {
+    if (pair_bound <= 0) return hipSuccess;
+    const int64_t blocks = (pair_bound + 3) / 4;  // one wavefront per node, 4 per block
+    hipLaunchKernelGGL(walk_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
     return hipGetLastError();
 }
 
