@@ -21,7 +21,8 @@ struct par_context {
     // host mirrors
     std::vector<par_aabb> h_aabbs;
     std::vector<int32_t> h_pairs;  // (entity, bin) pairs each entity inserts, alt:243-267
-    int64_t total_pairs = 0;
+    std::vector<int32_t> h_tiles;  // render tiles each entity's screen rectangle can touch
+    int64_t total_pairs = 0, total_tiles = 0;
     int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
     bool have_light = false, have_entities = false;
     par_light light{};
@@ -91,6 +92,20 @@ int64_t pairs_of(const par_context* c, const par_aabb& a) {
     return (int64_t)(x1 - x0) * (y1 - y0) * (z1 - z0);
 }
 
+// Render tiles (bin-wide, PAR_NT / bin rows tall) the screen rectangle of one AABB can touch: an upper bound of the
+// tiles it puts on the work lists. Columns come from its x bins, rows from alt:314-317 (H - world_j).
+int64_t tiles_of(const par_context* c, const par_aabb& a) {
+    const int W = c->params.width, H = c->params.height, B = c->params.bin_size;
+    const int minx = a.px, maxx = a.px + a.ex;
+    if (maxx < 0 || minx >= W) return 0;
+    const int x0 = std::max(0, minx / B), x1 = std::min(c->gx, (maxx + B - 1) / B);
+    const int lo = std::max(0, H - (a.py + a.ey) - (a.pz + a.ez)), hi = std::min(H, H - a.py - a.pz);
+    if (x1 <= x0 || hi <= lo) return 0;
+    const int tr = PAR_NT / B, subs = c->grid.subs;
+    auto tile_row = [&](int j) { return (j / B) * subs + (j % B) / tr; };
+    return (int64_t)(x1 - x0) * (tile_row(hi - 1) - tile_row(lo) + 1);
+}
+
 bool extent_ok(const par_aabb& a) {
     // The sprite is 20 wide and 40 tall (alt:330, spr:67-71): texel row = (ey + ez) - 1 at most, column < ex.
     return a.ex >= 0 && a.ey >= 0 && a.ez >= 0 && a.ex <= PAR_SPRITE_W && (int)a.ey + (int)a.ez <= PAR_SPRITE_H;
@@ -103,10 +118,9 @@ void free_pool(par_context* c) {
         if (c->grid.node_bin[s]) (void)hipFree(c->grid.node_bin[s]);
         c->grid.node_entity[s] = c->grid.node_next[s] = c->grid.node_bin[s] = nullptr;
     }
-    if (c->grid.walk_cnt) (void)hipFree(c->grid.walk_cnt);
-    if (c->grid.walk_rec) (void)hipFree(c->grid.walk_rec);
-    c->grid.walk_cnt = nullptr;
-    c->grid.walk_rec = nullptr;
+    if (c->grid.colrec) (void)hipFree(c->grid.colrec);
+    c->grid.colrec = nullptr;
+    c->grid.col_capacity = 0;
     c->grid.capacity = 0;
 }
 
@@ -117,8 +131,9 @@ int reset_grid(par_context* ctx) {
         PAR_HIP(hipMemsetAsync(ctx->grid.head[s], 0, (size_t)ctx->volume * sizeof(int32_t), ctx->stream));
         PAR_HIP(hipMemsetAsync(ctx->grid.count[s], 0, (size_t)ctx->volume, ctx->stream));
         PAR_HIP(hipMemsetAsync(ctx->grid.colflag[s], 0, (size_t)ctx->gx * ctx->gy * sizeof(int32_t), ctx->stream));
+        PAR_HIP(hipMemsetAsync(ctx->grid.tileflag[s], 0, (size_t)ctx->gx * ctx->gy * ctx->grid.subs * sizeof(int32_t), ctx->stream));
     }
-    PAR_HIP(hipMemsetAsync(ctx->grid.ncols, 0, sizeof(int32_t), ctx->stream));
+    PAR_HIP(hipMemsetAsync(ctx->grid.counters, 0, 4 * sizeof(int32_t), ctx->stream));
     PAR_HIP(hipMemsetAsync(ctx->grid.node_counter, 0, 2 * sizeof(int32_t), ctx->stream));
     PAR_HIP(hipStreamSynchronize(ctx->stream));
     ctx->set = 0;
@@ -137,8 +152,10 @@ int ensure_pool(par_context* ctx, int64_t pairs) {
         PAR_HIP(hipMalloc(&ctx->grid.node_next[s], (size_t)cap * sizeof(int32_t)));
         PAR_HIP(hipMalloc(&ctx->grid.node_bin[s], (size_t)cap * sizeof(int32_t)));
     }
-    PAR_HIP(hipMalloc(&ctx->grid.walk_cnt, (size_t)cap * sizeof(int32_t)));
-    PAR_HIP(hipMalloc(&ctx->grid.walk_rec, (size_t)cap * PAR_WALK_CAP * sizeof(par_slot)));
+    // occupied columns <= (entity, bin) pairs: one column record each
+    const int64_t col_cap = std::min<int64_t>((int64_t)ctx->gx * ctx->gy, cap);
+    PAR_HIP(hipMalloc(&ctx->grid.colrec, (size_t)col_cap * sizeof(par_colrec)));
+    ctx->grid.col_capacity = (int32_t)col_cap;
     ctx->grid.capacity = (int32_t)cap;
     return reset_grid(ctx);
 }
@@ -186,7 +203,9 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.by_lo = row_begin / B;
     a.by_hi = (row_end - 1) / B;
     a.tile_rows = PAR_NT / B;
-    a.subs = (B + a.tile_rows - 1) / a.tile_rows;
+    a.subs = c->grid.subs;
+    a.set = set;
+    a.magic_tr = (uint32_t)((1ull << 32) / (uint64_t)a.tile_rows + 1ull);
     // every ray traced (as the reference does), or the lit plane requested: every column goes through the tracer
     a.dense = ((flags & PAR_RENDER_TRACE_BACKGROUND) || out.lit) ? 1 : 0;
     a.magic_b = (uint32_t)((1ull << 32) / (uint64_t)B + 1ull);
@@ -197,11 +216,10 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.dyn = make_dyn(c, c->light);
     a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;
     a.count = c->grid.count[set];
-    a.colflag = c->grid.colflag[set];
+    a.tileflag = c->grid.tileflag[set];
     a.slots = c->grid.slots;
     a.sprites = c->d_sprites;
     a.texinfo = c->d_texinfo;
-    a.head = c->grid.head[set];
     a.sprite_ids = c->d_sprite_ids;
     a.palette = c->d_palette;
     a.out = out;
@@ -232,18 +250,13 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
     // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
     PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
-    {
-        par_walk_args w{};
-        w.set = set;
-        w.dyn = r.dyn;
-        w.dyn_ptr = r.dyn_ptr;
-        PAR_HIP(par_launch_walk(ctx->grid, w, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
-    }
+    const int64_t all_tiles = (int64_t)ctx->gx * ctx->gy * ctx->grid.subs;
+    // occupied columns <= (entity, bin) pairs; a captured graph must also hold for later frames
+    PAR_HIP(par_launch_columns(ctx->grid, r, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
     PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
-    // occupied columns <= (entity, bin) pairs; future graph replays are only bounded by the pool
-    PAR_HIP(par_launch_render(ctx->grid, r, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
+    PAR_HIP(par_launch_render(ctx->grid, r, graph_mode ? all_tiles : ctx->total_tiles, graph_mode, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
 }
@@ -341,7 +354,17 @@ int par_create(const par_params* params, int device, par_context** out) {
         if ((e = hipMalloc(&ctx->grid.colflag[s], (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     }
     if ((e = hipMalloc(&ctx->grid.col_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
-    if ((e = hipMalloc(&ctx->grid.ncols, sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.counters, 4 * sizeof(int32_t))) != hipSuccess) return bail(e);
+    {
+        const int tr = PAR_NT / p.bin_size;
+        ctx->grid.subs = (p.bin_size + tr - 1) / tr;
+    }
+    const size_t n_tiles = (size_t)gx * gy * ctx->grid.subs;
+    for (int s = 0; s < 2; s++) {
+        if ((e = hipMalloc(&ctx->grid.tileflag[s], n_tiles * sizeof(int32_t))) != hipSuccess) return bail(e);
+    }
+    if ((e = hipMalloc(&ctx->grid.fast_list, n_tiles * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.slow_list, n_tiles * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.slots, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.node_counter, 2 * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->d_palette, PAR_MAX_PALETTE * sizeof(par_color))) != hipSuccess) return bail(e);
@@ -375,8 +398,13 @@ void par_destroy(par_context* ctx) {
         if (ctx->grid.count[s]) (void)hipFree(ctx->grid.count[s]);
         if (ctx->grid.colflag[s]) (void)hipFree(ctx->grid.colflag[s]);
     }
-    if (ctx->grid.col_list) (void)hipFree(ctx->grid.col_list);
-    if (ctx->grid.ncols) (void)hipFree(ctx->grid.ncols);
+    for (int s = 0; s < 2; s++) {
+        if (ctx->grid.tileflag[s]) (void)hipFree(ctx->grid.tileflag[s]);
+    }
+    void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.fast_list, ctx->grid.slow_list};
+    for (void* p : lists) {
+        if (p) (void)hipFree(p);
+    }
     void* ptrs[] = {ctx->grid.slots, ctx->grid.node_counter, ctx->d_palette, ctx->d_ray_counter, ctx->d_dyn,
                     ctx->d_aabbs, ctx->d_sprite_ids, ctx->d_sprites, ctx->d_texinfo};
     for (void* p : ptrs) {
@@ -444,13 +472,15 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
     drop_graphs(ctx);
-    std::vector<int32_t> pairs((size_t)n);
-    int64_t total = 0;
+    std::vector<int32_t> pairs((size_t)n), tiles((size_t)n);
+    int64_t total = 0, total_t = 0;
     for (int i = 0; i < n; i++) {
         const int64_t k = pairs_of(ctx, aabbs[i]);
         if (k > 0x7FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "entity spans too many bins");
         pairs[(size_t)i] = (int32_t)k;
         total += k;
+        tiles[(size_t)i] = (int32_t)tiles_of(ctx, aabbs[i]);
+        total_t += tiles[(size_t)i];
     }
     int rc = ensure_pool(ctx, total);
     if (rc != PAR_OK) return rc;
@@ -470,7 +500,9 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     }
     ctx->h_aabbs.assign(aabbs, aabbs + n);
     ctx->h_pairs.swap(pairs);
+    ctx->h_tiles.swap(tiles);
     ctx->total_pairs = total;
+    ctx->total_tiles = total_t;
     ctx->n_entities = n;
     ctx->max_sprite_id = max_id;
     ctx->have_entities = true;
@@ -511,10 +543,13 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    std::vector<int32_t> np((size_t)n);
+    std::vector<int32_t> np((size_t)n), nt((size_t)n);
+    int64_t total_t = ctx->total_tiles;
     for (int i = 0; i < n; i++) {
         np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i]);
         total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
+        nt[(size_t)i] = (int32_t)tiles_of(ctx, aabbs[i]);
+        total_t += nt[(size_t)i] - ctx->h_tiles[(size_t)(first + i)];
     }
     PAR_HIP(hipSetDevice(ctx->device));
     int rc = ensure_pool(ctx, total);
@@ -525,8 +560,10 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     for (int i = 0; i < n; i++) {
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
+        ctx->h_tiles[(size_t)(first + i)] = nt[(size_t)i];
     }
     ctx->total_pairs = total;
+    ctx->total_tiles = total_t;
     return PAR_OK;
 }
 
@@ -671,7 +708,7 @@ int par_get_stats(par_context* ctx, par_frame_stats* stats) {
     ctx->stats.shadow_rays = -1;
     {
         int32_t nc = 0;
-        PAR_HIP(hipMemcpy(&nc, ctx->grid.ncols, sizeof(nc), hipMemcpyDeviceToHost));
+        PAR_HIP(hipMemcpy(&nc, ctx->grid.counters + PAR_CNT_COLS, sizeof(nc), hipMemcpyDeviceToHost));
         ctx->stats.occupied_columns = nc;
     }
     if (ctx->last_flags & PAR_RENDER_COUNT_RAYS) {

@@ -24,8 +24,12 @@ constexpr int PAR_MAX_ENTRIES = 256;    // column slot records staged in LDS (th
 constexpr int PAR_MAX_OCC = 512;        // shadow-occluder records staged in LDS per round
 constexpr int PAR_CHAIN_MAX = 1024;     // walk iterations whose bin coordinates are staged in LDS at a time
 constexpr int PAR_PPT = 3;              // shadow-walk probes per thread per batch
-constexpr int PAR_WALK_CAP = 32;        // occluder records precomputed per start bin (longer lists: in-kernel walk)
-constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = PAR_NT;  // bin sizes the tile mapping supports
+// Per-column record built once per frame by columns_kernel and consumed by every tile of the column.
+constexpr int PAR_COL_NB = 16;          // occupied bins of one column it can describe
+constexpr int PAR_COL_ENT = 48;         // slot records of one column
+constexpr int PAR_BIN_WALK = 64;        // occluder records of one start bin's shadow walk
+constexpr int PAR_COL_WALK = 160;       // occluder records of all walks of one column
+constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = PAR_NT / 2;  // bin sizes the tile mapping supports (>= 2 rows per tile)
 
 // What the shading pass needs of a sprite texel besides its depth, in one 16-byte record: the normal (spr:70) and
 // the palette colour the texel's index resolves to (spr:68 through color_palette, alt:352-354). Built on the host
@@ -35,6 +39,22 @@ struct par_texel {
     uint32_t rgba;
 };
 static_assert(sizeof(par_texel) == 16, "texel record must stay 16 bytes");
+
+struct par_colrec_nb {
+    int16_t bz;          // bin_z of an occupied bin of the column, ascending
+    uint8_t off, cnt;    // its records: entries[off, off+cnt)
+    int16_t woff, wcnt;  // the shadow walk that starts in it: walk[woff, woff+wcnt)
+};
+struct par_colrec {
+    int16_t n_nb, n_entries, n_walk;
+    int16_t overflow;    // 1: the column does not fit this record; its tiles go to the generic kernel
+    int32_t col;         // bx * gy + by
+    int32_t pad_;
+    par_colrec_nb nb[PAR_COL_NB];
+    par_slot entries[PAR_COL_ENT];
+    par_slot walk[PAR_COL_WALK];
+};
+static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 
 // Per-frame values that change without the scene being re-uploaded. In the hipGraph path they live in device memory
 // (updated by a memcpy node); otherwise they travel as kernel arguments.
@@ -54,11 +74,14 @@ struct par_grid_dev {
     int32_t* node_bin[2];     // [capacity]
     int32_t* node_counter;    // [2]
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
-    int32_t* ncols;           // [1]
-    int32_t* walk_cnt;        // [capacity] per head node: occluder records found by the shadow walk from its bin,
-                              //            or -1 when the list did not fit (the render kernel then walks itself)
-    par_slot* walk_rec;       // [capacity * PAR_WALK_CAP]
+    int32_t* counters;        // [4]: occupied columns, fast tiles, generic tiles, spare (reset by insert)
+    int32_t* tileflag[2];     // [gx*gy*subs] 1 when a render kernel owns the tile (fill_kernel skips it)
+    par_colrec* colrec;       // [col_capacity] indexed like col_list
+    int32_t* fast_list;       // [gx*gy*subs] tiles (column index * subs + sub) for render_fast_kernel
+    int32_t* slow_list;       // [gx*gy*subs] tiles of overflowed columns for render_tiles_kernel
     int32_t capacity;
+    int32_t col_capacity;
+    int32_t subs;             // tiles per column
 };
 
 struct par_bin_args {
@@ -75,6 +98,7 @@ struct par_render_args {
     int32_t by_lo, by_hi;          // bin rows touched
     int32_t tile_rows;             // rows per workgroup tile: PAR_NT / B
     int32_t subs;                  // tiles per bin row = ceil(B / tile_rows)
+    int32_t set;                   // grid set of this frame
     int32_t dense;                 // 1: every column is rendered by render_tiles (every ray traced), no fill pass
     uint32_t magic_b;              // floor(n / B) == __umulhi(n, magic_b) for n * B < 2^32
     float ambient;
@@ -84,31 +108,28 @@ struct par_render_args {
     par_frame_dyn dyn;             // used when dyn_ptr == nullptr
     const par_frame_dyn* dyn_ptr;  // graph path
     const uint8_t* count;
-    const int32_t* colflag;
+    const int32_t* tileflag;
+    uint32_t magic_tr;             // floor(n / tile_rows) == __umulhi(n, magic_tr) for n < B
     const par_slot* slots;
     const par_sprite* sprites;
     const par_texel* texinfo;      // [n_sprites * 800]
-    const int32_t* head;           // this frame's list heads (start bin -> head node -> precomputed walk)
     const int32_t* sprite_ids;     // nullable
     const par_color* palette;
     par_outputs out;               // device pointers, addressing (row_begin, 0)
     unsigned long long* ray_counter;
 };
 
-struct par_walk_args {
-    int32_t set;
-    par_frame_dyn dyn;
-    const par_frame_dyn* dyn_ptr;
-};
+enum { PAR_CNT_COLS = 0, PAR_CNT_FAST = 1, PAR_CNT_SLOW = 2 };
 
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
-// Shadow walk from every occupied bin -> per-bin occluder lists (walk_cnt / walk_rec).
-hipError_t par_launch_walk(const par_grid_dev& g, const par_walk_args& a, int64_t pair_bound, hipStream_t stream);
-// Background for the columns no primitive shows in (skipped when a.dense).
+// Per occupied column: compact slot list, the shadow walks of its bins, and its tiles onto the work lists.
+hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
+// Background for every tile no render kernel owns (skipped when a.dense).
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
-// `column_bound`: an upper bound of the occupied columns in the row range (ignored when a.dense).
-hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
+// `tile_bound`: an upper bound of the tiles on the work lists (ignored when a.dense: every tile, generic kernel).
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t tile_bound, bool graph_mode,
+                             hipStream_t stream);
 
 #endif

@@ -1,12 +1,15 @@
 // par_kernels.hip — hand-written HIP kernels for gfx950 (MI355X / CDNA4).
 //
-// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is four launches:
+// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is six launches:
 //   bin_insert_kernel   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and deterministic
 //   bin_resolve_kernel  }   (+ which screen columns show any primitive this frame)
-//   fill_kernel         background pixels of columns no primitive shows in (alt:281 -> alt:735): pure streaming
-//   render_tiles_kernel trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, trace_hash_for_light
-//                       alt:399-500, AABB::intersect alt:40-83, Vector::normalize spr:28-35,
-//                       Color::operator* spr:8-16 -- for the occupied columns only
+//   columns_kernel      per occupied column: its compact slot list, the bin walks of trace_hash_for_light
+//                       (alt:399-500; they depend on the start bin only) and its tiles onto the work lists
+//   fill_kernel         background pixels of tiles no primitive reaches (alt:281 -> alt:735): pure streaming
+//   render_fast_kernel  trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect alt:40-83,
+//                       Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column records
+//   render_tiles_kernel the same, self-contained (walks in-kernel): overflowed columns, and every tile when every
+//                       ray is traced as the reference does
 //
 // Float discipline: compiled with -ffp-contract=off; divisions are hipcc's default correctly-rounded fp32
 // division; min/max are the ?: forms of std::min/std::max so NaN handling follows the reference (first argument
@@ -58,9 +61,11 @@ __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin
         const int b = g.node_bin[o][i];
         g.head[o][b] = 0;
         g.count[o][b] = 0;
-        g.colflag[o][b / g.gz] = 0;
+        const int col = b / g.gz;
+        g.colflag[o][col] = 0;
+        for (int t = 0; t < g.subs; t++) g.tileflag[o][col * g.subs + t] = 0;
     }
-    if (tid == 0) *g.ncols = 0;
+    if (tid < 3) g.counters[tid] = 0;
 
     const int W = a.W, H = a.H, L = a.L, B = a.B;
     const int lane = threadIdx.x & 63;
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bi
         const int col = b / g.gz;
         const int by = col % g.gy;
         if (atomicExch(&g.colflag[s][col], 1) == 0 && by >= a.by_lo && by <= a.by_hi) {
-            g.col_list[atomicAdd(g.ncols, 1)] = col;
+            g.col_list[atomicAdd(&g.counters[PAR_CNT_COLS], 1)] = col;
         }
     }
 }
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bi
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) { return wave_incl_scan_i(v, lane); }
 
-// Exclusive prefix sum over the workgroup; two barriers. `total` is uniform.
+// Exclusive prefix sum over a workgroup of NW wavefronts; two barriers. `total` is uniform.
+template <int NW>
 __device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum, int& total) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int incl = wave_incl_scan(v, lane);
@@ -189,7 +195,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum, int& total)
     int base = 0;
     total = 0;
 #pragma unroll
-    for (int i = 0; i < PAR_NT / 64; i++) {
+    for (int i = 0; i < NW; i++) {
         const int s = wsum[i];
         if (i < w) base += s;
         total += s;
@@ -255,101 +261,220 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// walk_kernel: the bin sequence trace_hash_for_light (alt:399-500) probes depends only on the start bin and the
-// light's bin, not on the ray. Shadow rays start in bins that hold primitives, so one wavefront per occupied bin
-// walks from it to the light ONCE per frame and records the slot records of every occupied bin on the way (the
-// start bin excluded, alt:471-473). A pixel whose ray starts there then only slab-tests that short list. The
-// reference's result is an OR over the probes, so neither probe order nor duplicates matter. Lists longer than
-// PAR_WALK_CAP are marked -1; the render kernel walks those itself.
+// columns_kernel: one workgroup (2 wavefronts) per occupied screen column (bx, by).
+//   A. the column's bins, front to back: compact list of the occupied ones and their slot records;
+//   B. one wavefront per occupied bin walks from it to the light as trace_hash_for_light does (alt:399-500). The
+//      probed bin sequence depends only on the start and light bins, not on the ray, so it is done ONCE per bin
+//      and frame: the slot records of every occupied bin on the way (start bin excluded, alt:471-473) are kept.
+//      A pixel whose shadow ray starts in that bin only slab-tests the short list; the reference's result is an
+//      OR over probes, so neither probe order nor duplicates matter;
+//   C. the record goes to HBM/L2 for the column's tiles; D. tiles some record can cover go onto the work list
+//      and are flagged so that fill_kernel leaves them alone.
+// A column that does not fit the record (PAR_COL_*) sends its tiles to the self-contained generic kernel.
 // ------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void walk_kernel(par_grid_dev g, par_walk_args a) {
-    __shared__ int16_t chain_all[4][3][65];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int16_t(*chain)[65] = chain_all[wave];
-    const int s = a.set;
-    const int node = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wave);
-    if (node >= min(g.node_counter[s], g.capacity)) return;
-    const int b0 = g.node_bin[s][node];
-    if (g.head[s][b0] != node + 1) return;  // one walk per bin: the list head's
-    const uint8_t* count = g.count[s];
-    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+struct ColShared {
+    par_colrec_nb nb[PAR_COL_NB];
+    par_slot entries[PAR_COL_ENT];
+    par_slot stage[2][PAR_BIN_WALK];  // per wavefront: the records of the walk it is doing
+    int16_t chain[2][3][65];
+    int32_t wsum[2];
+    int32_t n_walk;
+    int32_t overflow;
+};
 
-    const int sx = b0 / (g.gy * g.gz);
-    const int rem = b0 - sx * g.gy * g.gz;
-    const int sy = rem / g.gz, sz = rem - (rem / g.gz) * g.gz;
-    // alt:406-430
-    const float fsx = (float)sx, fsy = (float)sy, fsz = (float)sz;
-    const float ddx = (float)dyn.lbx - fsx, ddy = (float)dyn.lby - fsy, ddz = (float)dyn.lbz - fsz;
-    float largest = __builtin_fabsf(ddx);
-    if (largest < __builtin_fabsf(ddy)) largest = __builtin_fabsf(ddy);
-    if (largest < __builtin_fabsf(ddz)) largest = __builtin_fabsf(ddz);
-    const int m = (int)largest;  // alt:432
-    const float step_mine = ((lane == 0) ? ddx : ((lane == 1) ? ddy : ddz)) / largest;  // alt:423-425
-    float carry = (lane == 0) ? fsx : ((lane == 1) ? fsy : fsz);
-    par_slot* out = g.walk_rec + (size_t)node * PAR_WALK_CAP;
-    int total = 0;
-    bool overflow = false;
+__global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render_args a) {
+    __shared__ ColShared sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci = (int)blockIdx.x;
+    // the launch is sized by an upper bound of the occupied columns; both loads are issued together
+    const int n_cols = g.counters[PAR_CNT_COLS];
+    const int col = g.col_list[ci];
+    if (ci >= n_cols) return;
+    const int bx = col / g.gy, by = col - (col / g.gy) * g.gy;
+    const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
+    const int B = a.B, H = a.H;
+    if (tid == 0) {
+        sm.n_walk = 0;
+        sm.overflow = (ci >= g.col_capacity) ? 1 : 0;
+    }
 
-    for (int it0 = 0; it0 < m; it0 += 64) {
-        const int n_it = min(64, m - it0);
-        if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
-            float v = carry;
-            chain[lane][0] = (int16_t)(int)v;  // alt:468
-            for (int i = 1; i <= n_it; i++) {
-                v = v + step_mine;
-                chain[lane][i] = (int16_t)(int)v;
+    // ---- A: ordered compaction of the column ------------------------------------------------------------------
+    int nb_base = 0, ent_base = 0;
+    bool over = false;
+    for (int t0 = 0; t0 < g.gz; t0 += 128) {
+        const int t = t0 + tid;
+        const par_slot* src = a.slots + (size_t)(col_base + min(t, g.gz - 1)) * PAR_SLOTS;
+        const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;
+        const par_slot first = src[0];  // issued beside the count: most occupied bins hold one primitive
+        int total;
+        const int packed = block_excl_scan<2>(((c != 0) << 16) | c, sm.wsum, total);
+        const int nb_i = nb_base + (packed >> 16);
+        const int off = ent_base + (packed & 0xFFFF);
+        if (c != 0) {
+            if (nb_i < PAR_COL_NB && off + c <= PAR_COL_ENT) {
+                par_colrec_nb e;
+                e.bz = (int16_t)t; e.off = (uint8_t)off; e.cnt = (uint8_t)c; e.woff = 0; e.wcnt = 0;
+                sm.nb[nb_i] = e;
+                for (int k = 0; k < c; k++) sm.entries[off + k] = (k == 0) ? first : src[k];
+            } else {
+                over = true;
             }
-            carry = v;
         }
-        // same wavefront wrote and reads: LDS operations of one wavefront complete in order; keep the compiler
-        // from moving the reads above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        nb_base += total >> 16;
+        ent_base += total & 0xFFFF;
+    }
+    if (__syncthreads_or(over ? 1 : 0)) {
+        if (tid == 0) sm.overflow = 1;
+    }
+    __syncthreads();
+    const int n_nb = nb_base, n_entries = ent_base;
 
-        int idx[7], cnt[7];
-        int mine = 0;
+    // ---- B: the shadow walks, one wavefront per occupied bin --------------------------------------------------
+    if (!sm.overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
+        const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+        int16_t(*chain)[65] = sm.chain[wave];
+        par_slot* stage = sm.stage[wave];
+        for (int i = wave; i < n_nb; i += 2) {  // wave-uniform
+            const int sx = bx, sy = by, sz = sm.nb[i].bz;
+            const int b0 = col_base + sz;
+            // alt:406-430
+            const float fsx = (float)sx, fsy = (float)sy, fsz = (float)sz;
+            const float ddx = (float)dyn.lbx - fsx, ddy = (float)dyn.lby - fsy, ddz = (float)dyn.lbz - fsz;
+            float largest = __builtin_fabsf(ddx);
+            if (largest < __builtin_fabsf(ddy)) largest = __builtin_fabsf(ddy);
+            if (largest < __builtin_fabsf(ddz)) largest = __builtin_fabsf(ddz);
+            const int m = (int)largest;  // alt:432
+            const float step_mine = ((lane == 0) ? ddx : ((lane == 1) ? ddy : ddz)) / largest;  // alt:423-425
+            float carry = (lane == 0) ? fsx : ((lane == 1) ? fsy : fsz);
+            int n_rec = 0;
+            bool w_over = false;
+            for (int it0 = 0; it0 < m && !w_over; it0 += 64) {
+                const int n_it = min(64, m - it0);
+                if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
+                    float v = carry;
+                    chain[lane][0] = (int16_t)(int)v;  // alt:468
+                    for (int q = 1; q <= n_it; q++) {
+                        v = v + step_mine;
+                        chain[lane][q] = (int16_t)(int)v;
+                    }
+                    carry = v;
+                }
+                // written and read by the same wavefront: LDS operations of one wavefront complete in order; keep
+                // the compiler from moving the reads above the writes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+                // lane l takes walk iteration it0 + l: its 7 probes (alt:438-466) are the corners of the 2x2x2
+                // block spanned by bin(tmp) and bin(tmp + step), minus bin(tmp) itself
+                int idx[7], cnt[7];
+                int mine = 0;
+                {
+                    const int li = min(lane, n_it - 1);
+                    const int ax = chain[0][li], ay = chain[1][li], az = chain[2][li];
+                    const int qx = chain[0][li + 1], qy = chain[1][li + 1], qz = chain[2][li + 1];
+                    bool ok[7];
 #pragma unroll
-        for (int q = 0; q < 7; q++) {
-            idx[q] = 0;
-            cnt[q] = 0;
-        }
-        if (lane < n_it) {
-            const int ax = chain[0][lane], ay = chain[1][lane], az = chain[2][lane];
-            const int qx = chain[0][lane + 1], qy = chain[1][lane + 1], qz = chain[2][lane + 1];
+                    for (int q = 0; q < 7; q++) {
+                        const int mask = q + 1;
+                        // a probe whose stepped axes do not all change bin repeats another probe
+                        const bool canonical = (!(mask & 1) || qx != ax) && (!(mask & 2) || qy != ay) &&
+                                               (!(mask & 4) || qz != az);
+                        const int b = flat_index(g.gy, g.gz, (mask & 1) ? qx : ax, (mask & 2) ? qy : ay,
+                                                 (mask & 4) ? qz : az);
+                        // alt:471-473: the start bin is skipped; an out-of-range flat index reads as an empty bin
+                        // (alt:476)
+                        ok[q] = lane < n_it && canonical && b != b0 && b >= 0 && b < g.volume;
+                        idx[q] = ok[q] ? b : b0;
+                    }
+                    // the seven counts are loaded side by side (no branch between the loads)
 #pragma unroll
-            for (int q = 0; q < 7; q++) {
-                const int mask = q + 1;
-                const bool canonical = (!(mask & 1) || qx != ax) && (!(mask & 2) || qy != ay) &&
-                                       (!(mask & 4) || qz != az);
-                if (canonical) {
-                    const int b = flat_index(g.gy, g.gz, (mask & 1) ? qx : ax, (mask & 2) ? qy : ay,
-                                             (mask & 4) ? qz : az);
-                    if (b != b0 && b >= 0 && b < g.volume) {  // alt:471-473; out of range reads as empty (alt:476)
-                        idx[q] = b;
-                        cnt[q] = count[b];
+                    for (int q = 0; q < 7; q++) cnt[q] = a.count[idx[q]];
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {
+                        cnt[q] = ok[q] ? cnt[q] : 0;
+                        mine += cnt[q];
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
+                const int incl = wave_incl_scan_i(mine, lane);
+                const int wave_total = __shfl(incl, 63);
+                if (n_rec + wave_total > PAR_BIN_WALK) {
+                    w_over = true;
+                } else {
+                    int o = n_rec + incl - mine;
+#pragma unroll
+                    for (int q = 0; q < 7; q++) {
+                        for (int k = 0; k < cnt[q]; k++) stage[o++] = a.slots[(size_t)idx[q] * PAR_SLOTS + k];
+                    }
+                    n_rec += wave_total;
+                }
             }
-#pragma unroll
-            for (int q = 0; q < 7; q++) mine += cnt[q];
+            // reserve this bin's part of the column's walk area and copy the staged records out
+            int woff = 0;
+            if (lane == 0 && !w_over) woff = atomicAdd(&sm.n_walk, n_rec);
+            woff = __shfl(woff, 0);
+            if (w_over || woff + n_rec > PAR_COL_WALK) {
+                if (lane == 0) sm.overflow = 1;
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                par_slot* dst = g.colrec[ci].walk + woff;
+                for (int r = lane; r < n_rec; r += 64) dst[r] = stage[r];
+                if (lane == 0) {
+                    sm.nb[i].woff = (int16_t)woff;
+                    sm.nb[i].wcnt = (int16_t)n_rec;
+                }
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        const int incl = wave_incl_scan_i(mine, lane);
-        const int wave_total = __shfl(incl, 63);
-        if (total + wave_total > PAR_WALK_CAP) {
-            overflow = true;
-            break;
-        }
-        int o = total + incl - mine;
-#pragma unroll
-        for (int q = 0; q < 7; q++) {
-            for (int k = 0; k < cnt[q]; k++) out[o++] = g.slots[(size_t)idx[q] * PAR_SLOTS + k];
-        }
-        total += wave_total;
     }
-    if (lane == 0) g.walk_cnt[node] = overflow ? -1 : total;
+    __syncthreads();
+    const bool overflow = sm.overflow != 0;
+
+    // ---- C: the record ----------------------------------------------------------------------------------------
+    if (ci < g.col_capacity) {
+        par_colrec* rec = g.colrec + ci;
+        if (tid == 0) {
+            rec->n_nb = (int16_t)(overflow ? 0 : n_nb);
+            rec->n_entries = (int16_t)(overflow ? 0 : n_entries);
+            rec->n_walk = (int16_t)sm.n_walk;
+            rec->overflow = overflow ? 1 : 0;
+            rec->col = col;
+        }
+        if (!overflow) {
+            if (tid < n_nb) rec->nb[tid] = sm.nb[tid];
+            if (tid < n_entries) rec->entries[tid] = sm.entries[tid];
+        }
+    }
+
+    // ---- D: the column's tiles --------------------------------------------------------------------------------
+    const int c0 = bx * B, tw = min(B, a.W - c0);
+    for (int sub = tid; sub < a.subs; sub += 128) {
+        const int tile_r0 = by * B + sub * a.tile_rows;
+        const int r0 = max(tile_r0, a.row_begin);
+        const int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
+        if (r0 >= r1) continue;
+        bool covers = overflow;  // the generic kernel decides for itself
+        if (!overflow) {
+            const int wj_hi = H - r0, wj_lo = H - r1 + 1;  // world_j range of the tile's rows (alt:280)
+            for (int e = 0; e < n_entries; e++) {
+                const par_slot rec = sm.entries[e];
+                // alt:310-317 over the tile's pixel rectangle
+                covers |= (rec.px < c0 + tw) && (rec.px + rec.ex > c0) && (wj_hi > rec.py + rec.pz) &&
+                          (wj_lo <= rec.py + rec.ey + rec.pz + rec.ez);
+            }
+        }
+        if (covers) {
+            g.tileflag[a.set][col * g.subs + sub] = 1;
+            if (overflow) {
+                g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci * g.subs + sub;
+            } else {
+                g.fast_list[atomicAdd(&g.counters[PAR_CNT_FAST], 1)] = ci * g.subs + sub;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -372,20 +497,21 @@ __global__ __launch_bounds__(256) void fill_kernel(par_grid_dev g, par_render_ar
     for (int c = __builtin_amdgcn_readfirstlane((int)blockIdx.x * wpb + ((int)threadIdx.x >> 6)); c < n_chunks;
          c += (int)gridDim.x * wpb) {
         const int y = c / cpr, x0 = (c - y * cpr) << 9;
-        const int colrow = div_bin(y + a.row_begin, a.magic_b);
+        const int by = div_bin(y + a.row_begin, a.magic_b);
+        const int sub = (int)__umulhi((uint32_t)(y + a.row_begin - by * a.B), a.magic_tr);
         const size_t rowbase = (size_t)y * W;
         if (fb) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int x = x0 + h * 256 + lane * 4;
-                if (x < W && a.colflag[div_bin(x, a.magic_b) * g.gy + colrow] == 0) {
+                if (x < W && a.tileflag[(div_bin(x, a.magic_b) * g.gy + by) * g.subs + sub] == 0) {
                     *reinterpret_cast<uint4*>(fb + rowbase + x) = make_uint4(out_rgba, out_rgba, out_rgba, out_rgba);
                 }
             }
         }
         if (a.out.palidx) {
             const int x = x0 + lane * 8;
-            if (x < W && a.colflag[div_bin(x, a.magic_b) * g.gy + colrow] == 0) {
+            if (x < W && a.tileflag[(div_bin(x, a.magic_b) * g.gy + by) * g.subs + sub] == 0) {
                 *reinterpret_cast<uint2*>(a.out.palidx + rowbase + x) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             }
         }
@@ -405,12 +531,237 @@ __global__ __launch_bounds__(256) void fill_generic_kernel(par_grid_dev g, par_r
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
          p += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(p / W), x = (int)(p - (long long)y * W);
-        const int col = div_bin(x, a.magic_b) * g.gy + div_bin(y + a.row_begin, a.magic_b);
-        if (a.colflag[col] != 0) continue;
+        const int by = div_bin(y + a.row_begin, a.magic_b);
+        const int sub = (int)__umulhi((uint32_t)(y + a.row_begin - by * a.B), a.magic_tr);
+        if (a.tileflag[(div_bin(x, a.magic_b) * g.gy + by) * g.subs + sub] != 0) continue;
         if (do_fb && a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[p] = out_rgba;
         if (do_pal && a.out.palidx) a.out.palidx[p] = PAR_PALIDX_BACKGROUND;
         if (a.out.brightness) a.out.brightness[p] = a.ambient;
         if (a.out.gbuf) a.out.gbuf[p] = px;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Per-lane shadow walk: trace_hash_for_light (alt:399-500) exactly as written, for the rare pixel whose shadow ray
+// starts in a bin that holds no primitive (negative world z, sprite depths outside the box) in the fast kernel.
+// ------------------------------------------------------------------------------------------------------------
+__device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, int sx, int sy,
+                                 int sz, const par_frame_dyn& dyn, int self, int ox, int oy, int oz, float ix,
+                                 float iy, float iz) {
+    const float bsx = (float)sx, bsy = (float)sy, bsz = (float)sz;             // alt:406-408
+    const float dx = (float)dyn.lbx - bsx, dy = (float)dyn.lby - bsy, dz = (float)dyn.lbz - bsz;  // alt:410-416
+    float largest = __builtin_fabsf(dx);                                          // alt:419-421
+    if (largest < __builtin_fabsf(dy)) largest = __builtin_fabsf(dy);
+    if (largest < __builtin_fabsf(dz)) largest = __builtin_fabsf(dz);
+    const float stx = dx / largest, sty = dy / largest, stz = dz / largest;       // alt:423-425
+    float cx = bsx, cy = bsy, cz = bsz, tx = bsx, ty = bsy, tz = bsz;             // alt:427-428
+    int counter = 0;                                                              // alt:429
+    const int start = flat_index(g.gy, g.gz, sx, sy, sz);                         // alt:430
+    for (int i = 0; i < (int)largest;) {                                          // alt:432
+        cx = tx; cy = ty; cz = tz;                                                // alt:436
+        if (counter == 0) { cx = tx + stx; counter++; }                           // alt:438-440
+        else if (counter == 1) { cy = ty + sty; counter++; }                      // alt:441-443
+        else if (counter == 2) { cz = tz + stz; counter++; }                      // alt:444-446
+        else if (counter == 3) { cx = tx + stx; cy = ty + sty; counter++; }       // alt:447-450
+        else if (counter == 4) { cx = tx + stx; cz = tz + stz; counter++; }       // alt:451-454
+        else if (counter == 5) { cy = ty + sty; cz = tz + stz; counter++; }       // alt:455-458
+        else {                                                                    // alt:459-466
+            cx = cx + stx; cy = cy + sty; cz = cz + stz;
+            tx = cx; ty = cy; tz = cz;
+            counter = 0;
+            i++;
+        }
+        const int b = flat_index(g.gy, g.gz, (int)cx, (int)cy, (int)cz);          // alt:468-470
+        if (b == start) continue;                                                 // alt:471-473
+        if (b < 0 || b >= g.volume) continue;  // out-of-range flat index reads as an empty bin (alt:476)
+        const int cnt = count[b];
+        for (int j = 0; j < cnt; j++) {                                           // alt:480
+            const par_slot rec = slots[(size_t)b * PAR_SLOTS + j];
+            if (rec.entity == self) continue;                                     // alt:484-487
+            if (slab_hit(rec, ox, oy, oz, ix, iy, iz)) return false;              // alt:489-491
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// render_fast_kernel: workgroups of 5 wavefronts (one pixel per lane) stride over the fast work list. Everything a
+// tile needs about its column arrives in ONE contiguous record (columns_kernel): 16 bytes per lane, one barrier,
+// then the pixels run out of LDS -- while the record of the workgroup's NEXT tile is already on its way.
+// ------------------------------------------------------------------------------------------------------------
+
+struct FastShared {
+    par_colrec rec[2];                        // double buffered: the next tile's record is in flight
+    int32_t sprite_depth[PAR_SPRITE_TEXELS];  // depth table of sprite 0 (the hot lookup of the primary pass)
+};
+
+__global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par_render_args a) {
+    __shared__ FastShared sm;
+    const int tid = threadIdx.x;
+    const int W = a.W, H = a.H, B = a.B;
+    const int n_tiles = g.counters[PAR_CNT_FAST];
+    if ((int)blockIdx.x >= n_tiles) return;
+    const float ambient = a.ambient;
+    const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
+    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+    for (int t = tid; t < PAR_SPRITE_TEXELS; t += PAR_NT) sm.sprite_depth[t] = a.sprites[0].depth[t];
+    const int py = (int)__umulhi((uint32_t)tid, a.magic_b);
+    const int px = tid - py * B;
+
+    constexpr int NV = (int)(sizeof(par_colrec) / 16);  // 16-byte pieces of a record: one per lane
+    static_assert(NV <= PAR_NT, "one record piece per lane");
+    const int stride = (int)gridDim.x;
+    int w = (int)blockIdx.x;
+    int tile_next = g.fast_list[w];
+    int tile_next2 = (w + stride < n_tiles) ? g.fast_list[w + stride] : -1;
+    uint4 piece = make_uint4(0, 0, 0, 0);
+    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + tile_next / g.subs)[tid];
+    for (int buf = 0;; buf ^= 1, w += stride) {
+        const int tile = tile_next;
+        if (tid < NV) reinterpret_cast<uint4*>(&sm.rec[buf])[tid] = piece;
+        // One barrier per tile: the buffer written now was last read two tiles ago, and every lane has passed the
+        // previous tile's barrier since.
+        __syncthreads();
+        tile_next = tile_next2;
+        if (tile_next >= 0) {  // prefetch: the record of the next tile, and the list entry after it
+            if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + tile_next / g.subs)[tid];
+            tile_next2 = (w + 2 * stride < n_tiles) ? g.fast_list[w + 2 * stride] : -1;
+        }
+        const par_colrec& rec_ = sm.rec[buf];
+        const int ci = tile / g.subs, sub = tile - ci * g.subs;
+        const int col_id = rec_.col;
+        const int bx = col_id / g.gy, by = col_id - bx * g.gy;
+        const int tile_r0 = by * B + sub * a.tile_rows;
+        const int r0 = max(tile_r0, a.row_begin);
+        const int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
+        const int c0 = bx * B;
+        const int tw = min(B, W - c0);
+        const int col = c0 + px, row = tile_r0 + py;
+        const bool valid = (px < tw) && (row >= r0) && (row < r1);
+        const int n_nb = (a.flags & (1u << 24)) ? 0 : rec_.n_nb;  // bit 24: ablation (timing only), no primary pass
+
+        // ---- primary ray, alt:271-397 --------------------------------------------------------------------------
+        bool hit = false;
+        int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;  // background texel: y = z = 0, entity_index 0 (alt:281)
+        {
+            const int i = col;
+            const int world_j = (int)(int16_t)(H - row);  // alt:280
+            int adjacent = 0;                             // alt:282
+            int closest = INT_MIN;                        // alt:289
+            int prev_bz = -2;
+            bool done = !valid;
+            int w_ybase = 0, w_pz = 0, w_d = 0;
+            for (int n = 0; n < n_nb; n++) {
+                if (__all(done)) break;  // wavefront early-out (alt:372-374)
+                const par_colrec_nb nb = rec_.nb[n];
+                if (!done) {
+                    if (nb.bz != prev_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
+                    prev_bz = nb.bz;
+                    bool hit_in_bin = false;
+                    for (int s = 0; s < nb.cnt; s++) {
+                        const par_slot rec = rec_.entries[nb.off + s];
+                        const int top = rec.py + rec.ey + rec.pz + rec.ez;
+                        if (i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
+                            const int sprite_row = top - world_j;                         // alt:324-326
+                            const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
+                            const int sid = a.sprite_ids ? a.sprite_ids[rec.entity] : 0;  // alt:321-322
+                            const int d = (sid == 0) ? sm.sprite_depth[t] : a.sprites[sid].depth[t];
+                            const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
+                            if (closest >= depth) continue;                               // alt:344-346
+                            closest = depth;
+                            w_ybase = rec.py + rec.ey + rec.ez - sprite_row;              // alt:356-359
+                            w_pz = rec.pz;                                                // alt:360-361
+                            w_d = d;
+                            p_entity = rec.entity;                                        // alt:363
+                            p_tex = sid * PAR_SPRITE_TEXELS + t;
+                            hit = true;
+                            hit_in_bin = true;                                            // alt:365
+                        }
+                    }
+                    adjacent += hit_in_bin ? 1 : 0;  // alt:368
+                    if (adjacent >= 2) done = true;  // alt:372-374
+                }
+            }
+            if (hit) {
+                p_y = w_ybase - w_d;
+                p_z = w_pz + w_d;
+            }
+        }
+
+        // ---- shading, alt:704-758 ------------------------------------------------------------------------------
+        float nx = 0.f, ny = 0.f, nz = 0.f;
+        uint32_t rgba = bg_rgba;
+        int pal_index = PAR_PALIDX_BACKGROUND;
+        float bright = ambient;  // background: min(1, max(0, 0 * t) + ambient) either way (SURVEY a-6), ray skipped
+        if (hit && !(a.flags & (1u << 26))) {  // bit 26: ablation (timing experiments only), no shading
+            const par_texel ti = a.texinfo[p_tex];  // normal (alt:349-350) + resolved palette colour (alt:352-354)
+            nx = ti.nx; ny = ti.ny; nz = ti.nz;
+            rgba = ti.rgba;
+            if (a.out.palidx) {
+                const int sid = p_tex / PAR_SPRITE_TEXELS;
+                pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
+            }
+            const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
+            // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
+            const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
+            const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
+            const float tx = dx / len, ty = dy / len, tz = dz / len;
+            const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
+            const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
+            const float diffuse = std_max(0.f, dot);                           // alt:745
+            const float b_lit = std_min(1.f, diffuse + ambient);               // alt:758
+            const int sy = div_bin(H - wy - wz, a.magic_b);                    // alt:725-726
+            const int sz = div_bin(wz, a.magic_b);                             // alt:727
+            const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
+            // shadow ray, alt:738-742: the walk from the start bin was done by columns_kernel
+            bool lit = true;
+            int wi = -1;
+            if (sy == by) {
+                for (int n = 0; n < n_nb; n++) {
+                    if (rec_.nb[n].bz == sz) wi = n;
+                }
+            }
+            if (wi >= 0) {
+                const int woff = rec_.nb[wi].woff, wcnt = rec_.nb[wi].wcnt;
+                for (int r = 0; r < wcnt; r++) {
+                    const par_slot rec = rec_.walk[woff + r];
+                    if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
+                        lit = false;
+                        break;
+                    }
+                }
+            } else {
+                lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y, inv_z);
+            }
+            bright = lit ? b_lit : ambient;
+        }
+        if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
+            const unsigned long long m = __ballot(valid && hit);
+            if ((tid & 63) == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
+        }
+
+        // ---- quantise + store, alt:735, 757-758 ----------------------------------------------------------------
+        if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
+            asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
+        } else if (valid) {
+            const size_t o = (size_t)(row - a.row_begin) * W + col;
+            if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
+            if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
+            if (a.out.brightness) a.out.brightness[o] = bright;
+            if (a.out.gbuf) {
+                par_pixel pxl;
+                pxl.normal = par_vec3{nx, ny, nz};
+                pxl.color.red = (uint8_t)(rgba & 0xFF);
+                pxl.color.green = (uint8_t)((rgba >> 8) & 0xFF);
+                pxl.color.blue = (uint8_t)((rgba >> 16) & 0xFF);
+                pxl.color.alpha = (uint8_t)(rgba >> 24);
+                pxl.y = p_y;
+                pxl.z = p_z;
+                pxl.entity_index = p_entity;
+                a.out.gbuf[o] = pxl;
+            }
+        }
+        if (tile_next < 0) break;
     }
 }
 
@@ -432,26 +783,10 @@ struct TileShared {
     int32_t nocc[3];
 };
 
-__global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, par_render_args a) {
-    __shared__ TileShared sm;
+__device__ void render_tile_generic(const par_grid_dev& g, const par_render_args& a, TileShared& sm, int bx, int by,
+                                    int sub) {
     const int tid = threadIdx.x;
     const int W = a.W, H = a.H, B = a.B;
-
-    // ---- tile decode (uniform) ----------------------------------------------------------------------------
-    const int wg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int ci = wg / a.subs, sub = wg - ci * a.subs;
-    int bx, by;
-    if (a.dense) {
-        by = a.by_lo + ci / g.gx;  // x fastest: neighbours in x share lines of the frame
-        bx = ci - (ci / g.gx) * g.gx;
-    } else {
-        // the launch is sized by an upper bound of the occupied columns; both loads are issued together
-        const int n_cols = *g.ncols;
-        const int col = g.col_list[ci];
-        if (ci >= n_cols) return;
-        bx = col / g.gy;
-        by = col - bx * g.gy;
-    }
     const int tile_r0 = by * B + sub * a.tile_rows;
     const int r0 = max(tile_r0, a.row_begin);
     const int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
@@ -487,7 +822,7 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
         const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;  // consecutive bytes: coalesced
         const par_slot first = src[0];
         int total;
-        const int packed = block_excl_scan(((c != 0) << 16) | c, sm.wsum, total);
+        const int packed = block_excl_scan<PAR_NT / 64>(((c != 0) << 16) | c, sm.wsum, total);
         const int nb_i = nb_base + (packed >> 16);
         const int off = ent_base + (packed & 0xFFFF);
         if (c != 0) {
@@ -630,28 +965,7 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
     }
     const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
 
-    // ---- phase 4a: the precomputed walk of the pixel's start bin (walk_kernel) -------------------------------
-    if (pend && !(a.flags & (1u << 28))) {  // bit 28: ablation, force the in-kernel walk
-        const int sy0 = ((key >> 16) & 0x7FFF) - 16384, sz0 = (key & 0xFFFF) - 32768;
-        const int sidx = flat_index(g.gy, g.gz, bx, sy0, sz0);
-        const int node = (sidx >= 0 && sidx < g.volume) ? a.head[sidx] - 1 : -1;
-        const int n_rec = (node >= 0) ? g.walk_cnt[node] : -1;
-        if (n_rec >= 0) {
-            const par_slot* recs = g.walk_rec + (size_t)node * PAR_WALK_CAP;
-            for (int r = 0; r < n_rec; r++) {
-                const par_slot rec = recs[r];
-                if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
-                    lit = false;
-                    break;
-                }
-            }
-            pend = false;  // resolved; pixels left pending take the in-kernel walk below
-        }
-    }
-
-    // ---- phase 4b: in-kernel shadow walk, alt:738-742 + alt:399-500 ----------------------------------------
-    // For pixels without a precomputed list (start bin holds no primitive: background rays when every ray is
-    // traced, negative world z, exotic sprite depths; or the list overflowed).
+    // ---- phase 4: shadow rays, alt:738-742 + alt:399-500 ---------------------------------------------------
     // Pixels of the tile whose walk starts in the same bin visit the same bins (the probe sequence depends only on
     // the start and light bins), so the walk is done once per distinct start bin by the whole workgroup; the
     // occupied bins it finds are staged in LDS and every pixel of the group slab-tests that list. The result of
@@ -788,6 +1102,34 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
     }
 }
 
+// The generic tile kernel: the tiles of overflowed columns (work list), or every tile of the row range when every
+// ray is traced as the reference does (a.dense). Workgroups stride over the tiles when the grid was capped.
+__global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, par_render_args a) {
+    __shared__ TileShared sm;
+    if (a.dense) {
+        const int total = g.gx * (a.by_hi - a.by_lo + 1) * a.subs;
+        const bool one_pass = (int)gridDim.x == total;
+        for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
+            const int wg = one_pass ? xcd_remap(w, total) : w;
+            const int ci = wg / a.subs, sub = wg - ci * a.subs;
+            const int by = a.by_lo + ci / g.gx;  // x fastest: neighbours in x share lines of the frame
+            const int bx = ci - (ci / g.gx) * g.gx;
+            render_tile_generic(g, a, sm, bx, by, sub);
+            __syncthreads();
+        }
+    } else {
+        const int n_tiles = g.counters[PAR_CNT_SLOW];
+        for (int w = (int)blockIdx.x; w < n_tiles; w += (int)gridDim.x) {
+            const int tile = g.slow_list[w];
+            const int ci = tile / g.subs, sub = tile - ci * g.subs;
+            const int col = g.col_list[ci];
+            const int bx = col / g.gy, by = col - (col / g.gy) * g.gy;
+            render_tile_generic(g, a, sm, bx, by, sub);
+            __syncthreads();
+        }
+    }
+}
+
 }  // namespace
 
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream) {
@@ -814,10 +1156,13 @@ hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, 
     return hipGetLastError();
 }
 
-hipError_t par_launch_walk(const par_grid_dev& g, const par_walk_args& a, int64_t pair_bound, hipStream_t stream) {
-    if (pair_bound <= 0) return hipSuccess;
-    const int64_t blocks = (pair_bound + 3) / 4;  // one wavefront per node, 4 per block
-    hipLaunchKernelGGL(walk_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                              hipStream_t stream) {
+    if (a.dense) return hipSuccess;
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    const int64_t blocks = column_bound < cols_in_range ? column_bound : cols_in_range;
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, g, a);
     return hipGetLastError();
 }
 
@@ -851,13 +1196,29 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
     return hipSuccess;
 }
 
-hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t tile_bound, bool graph_mode,
                              hipStream_t stream) {
-    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
-    const int64_t cols = a.dense ? cols_in_range : (column_bound < cols_in_range ? column_bound : cols_in_range);
-    const int64_t blocks = cols * a.subs;
-    if (blocks <= 0) return hipSuccess;
-    if (blocks > 0x7FFFFFFF) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)blocks), dim3(PAR_NT), 0, stream, g, a);
+    const int64_t tiles_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1) * a.subs;
+    if (tiles_in_range <= 0 || tiles_in_range > 0x7FFFFFFF) return hipErrorInvalidValue;
+    if (a.dense) {
+        hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)tiles_in_range), dim3(PAR_NT), 0, stream, g, a);
+        return hipGetLastError();
+    }
+    int64_t bound = tile_bound < tiles_in_range ? tile_bound : tiles_in_range;
+    if (bound <= 0) return hipSuccess;
+    // The work lists live on the device. Outside a graph the host knows a tight bound (the tiles the boxes'
+    // screen rectangles can touch): one workgroup per listed tile, the few extra ones exit at once. A captured
+    // graph must hold for later frames too: cap the grid and let the workgroups stride over the list.
+    // 5 resident workgroups per CU (70 VGPRs -> 7 wavefronts per SIMD): more would only queue behind them, and a
+    // workgroup that takes several tiles overlaps the next record's load with the current tile's pixels
+    const int64_t cap = (int64_t)256 * 5;
+    const int64_t fast_blocks = bound > cap ? cap : bound;
+    (void)graph_mode;
+    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)fast_blocks), dim3(PAR_NT), 0, stream, g, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // overflowed columns are the exception: a small strided grid
+    const int64_t slow_blocks = bound < 512 ? bound : 512;
+    hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)slow_blocks), dim3(PAR_NT), 0, stream, g, a);
     return hipGetLastError();
 }

@@ -35,18 +35,17 @@ W = H = L = 4096
 p = T.default_params(W, H, L)
 a, l = par.scene_synthetic(1024, W, H, L, 12345)
 run("4096 synthetic1024", p, a, l)
-run("4096 synthetic1024 no-shadow", p, a, l, flags=1 << 30)
-run("4096 synthetic1024 no-primary no-shadow", p, a, l, flags=(1 << 30) | (1 << 29))
-run("4096 synthetic1024 trace-bg", p, a, l, flags=1)
+run("4096 synthetic1024 no-walks(27)", p, a, l, flags=1 << 27)
+run("4096 synthetic1024 no-shading(26)", p, a, l, flags=1 << 26)
+run("4096 synthetic1024 no-walks no-shading", p, a, l, flags=(1 << 26) | (1 << 27))
+run("4096 synthetic1024 no-stores(25)", p, a, l, flags=(1 << 25))
+run("4096 synthetic1024 no-primary(24) no-shading", p, a, l, flags=(1 << 24) | (1 << 26))
+run("4096 synthetic1024 no-primary no-shading no-stores", p, a, l, flags=(1 << 24) | (1 << 25) | (1 << 26))
 run("4096 empty scene (fill only)", p, a[:0], l)
-run("4096 fb only", p, a, l, planes=("fb",))
-# dense: full floor of 20x20x20 tiles
 rows = [(i * 20, 0, j * 20, 20, 20, 20) for i in range(W // 20) for j in range(L // 20)]
 fl = T.make_aabbs(rows)
 run("4096 full floor (41943 prims)", p, fl, l)
-run("4096 full floor no-shadow", p, fl, l, flags=1 << 30)
-p2 = T.default_params(2048, 2048, 2048)
-a2, l2 = par.scene_synthetic(256, 2048, 2048, 2048, 12345)
-run("2048 synthetic256", p2, a2, l2)
+run("4096 full floor no-walks", p, fl, l, flags=1 << 27)
 p3 = T.default_params()
 run("480x320 default graybox", p3, par.scene_graybox(), T.make_light(480, 160, 80))
+run("480x320 default graybox no-walks", p3, par.scene_graybox(), T.make_light(480, 160, 80), flags=1 << 27)
