@@ -5,6 +5,7 @@
 // frame = bin + trace + shade (alt:690-760) per render call. There is no CPU rendering path in this library.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -16,7 +17,9 @@ struct par_context {
     par_params params{};
     int device = 0;
     int gx = 0, gy = 0, gz = 0, volume = 0;
-    hipStream_t stream = nullptr;  // used by the synchronous host-buffer entry points
+    hipStream_t stream = nullptr;   // used by the synchronous host-buffer entry points
+    hipStream_t stream2 = nullptr;  // the background fill runs here, beside the hash build
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // host mirrors
     std::vector<par_aabb> h_aabbs;
@@ -131,7 +134,6 @@ int reset_grid(par_context* ctx) {
         PAR_HIP(hipMemsetAsync(ctx->grid.head[s], 0, (size_t)ctx->volume * sizeof(int32_t), ctx->stream));
         PAR_HIP(hipMemsetAsync(ctx->grid.count[s], 0, (size_t)ctx->volume, ctx->stream));
         PAR_HIP(hipMemsetAsync(ctx->grid.colflag[s], 0, (size_t)ctx->gx * ctx->gy * sizeof(int32_t), ctx->stream));
-        PAR_HIP(hipMemsetAsync(ctx->grid.tileflag[s], 0, (size_t)ctx->gx * ctx->gy * ctx->grid.subs * sizeof(int32_t), ctx->stream));
     }
     PAR_HIP(hipMemsetAsync(ctx->grid.counters, 0, 4 * sizeof(int32_t), ctx->stream));
     PAR_HIP(hipMemsetAsync(ctx->grid.node_counter, 0, 2 * sizeof(int32_t), ctx->stream));
@@ -216,7 +218,6 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.dyn = make_dyn(c, c->light);
     a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;
     a.count = c->grid.count[set];
-    a.tileflag = c->grid.tileflag[set];
     a.slots = c->grid.slots;
     a.sprites = c->d_sprites;
     a.texinfo = c->d_texinfo;
@@ -246,17 +247,31 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
     }
+    // The background fill does not depend on the hash: it runs on a second stream beside the build and joins before
+    // the render kernels overwrite the tiles primitives reach. (Timed runs keep everything on one stream so that
+    // the event pairs bracket single kernels.)
+    const bool fork = !ev && !r.dense;
+    if (fork) {
+        PAR_HIP(hipEventRecord(ctx->ev_fork, stream));
+        PAR_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+        PAR_HIP(par_launch_fill(ctx->grid, r, ctx->stream2));
+        PAR_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+    }
     if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
     PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
     // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
     PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
-    const int64_t all_tiles = (int64_t)ctx->gx * ctx->gy * ctx->grid.subs;
-    // occupied columns <= (entity, bin) pairs; a captured graph must also hold for later frames
-    PAR_HIP(par_launch_columns(ctx->grid, r, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
+    // occupied columns <= (entity, bin) pairs
+    const int64_t col_bound = graph_mode ? ctx->grid.capacity : ctx->total_pairs;
+    PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
-    PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    if (fork) {
+        PAR_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
+    } else {
+        PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    }
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
-    PAR_HIP(par_launch_render(ctx->grid, r, graph_mode ? all_tiles : ctx->total_tiles, graph_mode, stream));
+    PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
 }
@@ -355,16 +370,23 @@ int par_create(const par_params* params, int device, par_context** out) {
     }
     if ((e = hipMalloc(&ctx->grid.col_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.counters, 4 * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if (const char* dbg = std::getenv("PAR_DEBUG_STAMPS"); dbg && dbg[0] == '1') {
+        const size_t bytes = (size_t)2 * PAR_STAMP_WGS * PAR_STAMP_SLOTS * sizeof(unsigned long long);
+        if ((e = hipMalloc(&ctx->grid.stamps, bytes)) != hipSuccess) return bail(e);
+        if ((e = hipMemset(ctx->grid.stamps, 0, bytes)) != hipSuccess) return bail(e);
+    }
     {
         const int tr = PAR_NT / p.bin_size;
         ctx->grid.subs = (p.bin_size + tr - 1) / tr;
     }
-    const size_t n_tiles = (size_t)gx * gy * ctx->grid.subs;
-    for (int s = 0; s < 2; s++) {
-        if ((e = hipMalloc(&ctx->grid.tileflag[s], n_tiles * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if (ctx->grid.subs > PAR_MAX_SUBS) {
+        par_destroy(ctx);
+        return PAR_ERR_UNSUPPORTED;
     }
-    if ((e = hipMalloc(&ctx->grid.fast_list, n_tiles * sizeof(int32_t))) != hipSuccess) return bail(e);
-    if ((e = hipMalloc(&ctx->grid.slow_list, n_tiles * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.slow_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.slots, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.node_counter, 2 * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->d_palette, PAR_MAX_PALETTE * sizeof(par_color))) != hipSuccess) return bail(e);
@@ -398,10 +420,10 @@ void par_destroy(par_context* ctx) {
         if (ctx->grid.count[s]) (void)hipFree(ctx->grid.count[s]);
         if (ctx->grid.colflag[s]) (void)hipFree(ctx->grid.colflag[s]);
     }
-    for (int s = 0; s < 2; s++) {
-        if (ctx->grid.tileflag[s]) (void)hipFree(ctx->grid.tileflag[s]);
-    }
-    void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.fast_list, ctx->grid.slow_list};
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.slow_list, ctx->grid.stamps};
     for (void* p : lists) {
         if (p) (void)hipFree(p);
     }
@@ -717,6 +739,15 @@ int par_get_stats(par_context* ctx, par_frame_stats* stats) {
         ctx->stats.shadow_rays = (int64_t)v;
     }
     *stats = ctx->stats;
+    return PAR_OK;
+}
+
+// Internal profiling aid (not part of the public header): copy the debug stamp buffer out (PAR_DEBUG_STAMPS=1).
+int par_debug_read_stamps(par_context* ctx, unsigned long long* out, size_t count) {
+    if (!ctx || !out || !ctx->grid.stamps) return PAR_ERR_NOT_READY;
+    const size_t n = (size_t)2 * PAR_STAMP_WGS * PAR_STAMP_SLOTS;
+    if (hipDeviceSynchronize() != hipSuccess) return PAR_ERR_HIP;
+    if (hipMemcpy(out, ctx->grid.stamps, (count < n ? count : n) * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return PAR_ERR_HIP;
     return PAR_OK;
 }
 

@@ -17,6 +17,9 @@ struct par_slot {
 };
 static_assert(sizeof(par_slot) == 16, "slot record must stay 16 bytes");
 
+constexpr int PAR_STAMP_SLOTS = 8;      // time stamps per workgroup in the debug stamp buffer
+constexpr int PAR_STAMP_WGS = 8192;     // workgroups per kernel that get a row in it
+
 // Kernel geometry (see DESIGN.md "kernels").
 constexpr int PAR_NT = 320;             // threads per render workgroup = 5 wavefronts, one pixel per thread
 constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count the LDS column list is sized for
@@ -47,14 +50,17 @@ struct par_colrec_nb {
 };
 struct par_colrec {
     int16_t n_nb, n_entries, n_walk;
-    int16_t overflow;    // 1: the column does not fit this record; its tiles go to the generic kernel
+    int16_t overflow;    // 1: the column does not fit this record; the generic kernel renders its tiles
     int32_t col;         // bx * gy + by
-    int32_t pad_;
+    uint32_t cover[3];   // bit s: some record can cover a pixel of tile s of the column (and s is in the row range)
+    int32_t pad_[2];
     par_colrec_nb nb[PAR_COL_NB];
+    int16_t ebz[PAR_COL_ENT];  // bin_z of each entry (the primary pass walks the entries as one flat list)
     par_slot entries[PAR_COL_ENT];
     par_slot walk[PAR_COL_WALK];
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
+constexpr int PAR_MAX_SUBS = 96;  // tiles per column the cover mask can describe
 
 // Per-frame values that change without the scene being re-uploaded. In the hipGraph path they live in device memory
 // (updated by a memcpy node); otherwise they travel as kernel arguments.
@@ -74,11 +80,10 @@ struct par_grid_dev {
     int32_t* node_bin[2];     // [capacity]
     int32_t* node_counter;    // [2]
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
-    int32_t* counters;        // [4]: occupied columns, fast tiles, generic tiles, spare (reset by insert)
-    int32_t* tileflag[2];     // [gx*gy*subs] 1 when a render kernel owns the tile (fill_kernel skips it)
+    int32_t* counters;        // [4]: occupied columns, overflowed columns, spare (reset by insert)
     par_colrec* colrec;       // [col_capacity] indexed like col_list
-    int32_t* fast_list;       // [gx*gy*subs] tiles (column index * subs + sub) for render_fast_kernel
-    int32_t* slow_list;       // [gx*gy*subs] tiles of overflowed columns for render_tiles_kernel
+    int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
+    unsigned long long* stamps;  // debug (PAR_DEBUG_STAMPS=1): per workgroup phase time stamps, else nullptr
     int32_t capacity;
     int32_t col_capacity;
     int32_t subs;             // tiles per column
@@ -108,7 +113,6 @@ struct par_render_args {
     par_frame_dyn dyn;             // used when dyn_ptr == nullptr
     const par_frame_dyn* dyn_ptr;  // graph path
     const uint8_t* count;
-    const int32_t* tileflag;
     uint32_t magic_tr;             // floor(n / tile_rows) == __umulhi(n, magic_tr) for n < B
     const par_slot* slots;
     const par_sprite* sprites;
@@ -119,17 +123,18 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
-enum { PAR_CNT_COLS = 0, PAR_CNT_FAST = 1, PAR_CNT_SLOW = 2 };
+enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1 };
 
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
 // Per occupied column: compact slot list, the shadow walks of its bins, and its tiles onto the work lists.
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
-// Background for every tile no render kernel owns (skipped when a.dense).
+// Background for every pixel of the row range (skipped when a.dense); the render kernels then overwrite the tiles
+// primitives reach. Independent of the hash: may run beside the build on another stream.
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
-// `tile_bound`: an upper bound of the tiles on the work lists (ignored when a.dense: every tile, generic kernel).
-hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t tile_bound, bool graph_mode,
+// `column_bound`: an upper bound of the occupied columns (ignored when a.dense: every tile, generic kernel).
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                              hipStream_t stream);
 
 #endif

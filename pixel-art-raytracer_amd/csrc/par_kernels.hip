@@ -20,6 +20,14 @@
 
 namespace {
 
+// Debug time stamps (PAR_DEBUG_STAMPS=1): lane 0 of a workgroup notes the 100 MHz wall clock at phase boundaries
+// into a buffer of its own; nothing the kernels compute reads it. `k` = kernel row, `i` = stamp slot.
+__device__ __forceinline__ void stamp(const par_grid_dev& g, int k, int i) {
+    if (g.stamps && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
+        g.stamps[((size_t)k * PAR_STAMP_WGS + blockIdx.x) * PAR_STAMP_SLOTS + i] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
 __device__ __forceinline__ int flat_index(int gy, int gz, int x, int y, int z) {
     return x * gy * gz + y * gz + z;  // index_into_view_hash alt:180-182
 }
@@ -61,11 +69,9 @@ __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin
         const int b = g.node_bin[o][i];
         g.head[o][b] = 0;
         g.count[o][b] = 0;
-        const int col = b / g.gz;
-        g.colflag[o][col] = 0;
-        for (int t = 0; t < g.subs; t++) g.tileflag[o][col * g.subs + t] = 0;
+        g.colflag[o][b / g.gz] = 0;
     }
-    if (tid < 3) g.counters[tid] = 0;
+    if (tid < 2) g.counters[tid] = 0;
 
     const int W = a.W, H = a.H, L = a.L, B = a.B;
     const int lane = threadIdx.x & 63;
@@ -174,7 +180,14 @@ __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bi
         const int col = b / g.gz;
         const int by = col % g.gy;
         if (atomicExch(&g.colflag[s][col], 1) == 0 && by >= a.by_lo && by <= a.by_hi) {
-            g.col_list[atomicAdd(&g.counters[PAR_CNT_COLS], 1)] = col;
+            // one atomic per wavefront on the shared counter (the lanes that got here take consecutive slots)
+            const unsigned long long m = __ballot(1);
+            const int leader = __ffsll((long long)m) - 1;
+            const int lane = threadIdx.x & 63;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&g.counters[PAR_CNT_COLS], __popcll(m));
+            base = __shfl(base, leader);
+            g.col_list[base + __popcll(m & ((1ull << lane) - 1ull))] = col;
         }
     }
 }
@@ -276,6 +289,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 struct ColShared {
     par_colrec_nb nb[PAR_COL_NB];
     par_slot entries[PAR_COL_ENT];
+    int16_t ebz[PAR_COL_ENT];
     par_slot stage[2][PAR_BIN_WALK];  // per wavefront: the records of the walk it is doing
     int16_t chain[2][3][65];
     int32_t wsum[2];
@@ -287,13 +301,14 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
     __shared__ ColShared sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = (int)blockIdx.x;
+    stamp(g, 0, 0);
     // the launch is sized by an upper bound of the occupied columns; both loads are issued together
     const int n_cols = g.counters[PAR_CNT_COLS];
     const int col = g.col_list[ci];
     if (ci >= n_cols) return;
+    stamp(g, 0, 1);
     const int bx = col / g.gy, by = col - (col / g.gy) * g.gy;
     const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
-    const int B = a.B, H = a.H;
     if (tid == 0) {
         sm.n_walk = 0;
         sm.overflow = (ci >= g.col_capacity) ? 1 : 0;
@@ -306,7 +321,6 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
         const int t = t0 + tid;
         const par_slot* src = a.slots + (size_t)(col_base + min(t, g.gz - 1)) * PAR_SLOTS;
         const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;
-        const par_slot first = src[0];  // issued beside the count: most occupied bins hold one primitive
         int total;
         const int packed = block_excl_scan<2>(((c != 0) << 16) | c, sm.wsum, total);
         const int nb_i = nb_base + (packed >> 16);
@@ -316,7 +330,10 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
                 par_colrec_nb e;
                 e.bz = (int16_t)t; e.off = (uint8_t)off; e.cnt = (uint8_t)c; e.woff = 0; e.wcnt = 0;
                 sm.nb[nb_i] = e;
-                for (int k = 0; k < c; k++) sm.entries[off + k] = (k == 0) ? first : src[k];
+                for (int k = 0; k < c; k++) {
+                    sm.entries[off + k] = src[k];
+                    sm.ebz[off + k] = (int16_t)t;
+                }
             } else {
                 over = true;
             }
@@ -329,6 +346,7 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
     }
     __syncthreads();
     const int n_nb = nb_base, n_entries = ent_base;
+    stamp(g, 0, 2);
 
     // ---- B: the shadow walks, one wavefront per occupied bin --------------------------------------------------
     if (!sm.overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
@@ -432,6 +450,7 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
     }
     __syncthreads();
     const bool overflow = sm.overflow != 0;
+    stamp(g, 0, 3);
 
     // ---- C: the record ----------------------------------------------------------------------------------------
     if (ci < g.col_capacity) {
@@ -442,50 +461,30 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
             rec->n_walk = (int16_t)sm.n_walk;
             rec->overflow = overflow ? 1 : 0;
             rec->col = col;
+            rec->cover[0] = rec->cover[1] = rec->cover[2] = 0;
         }
         if (!overflow) {
             if (tid < n_nb) rec->nb[tid] = sm.nb[tid];
-            if (tid < n_entries) rec->entries[tid] = sm.entries[tid];
-        }
-    }
-
-    // ---- D: the column's tiles --------------------------------------------------------------------------------
-    const int c0 = bx * B, tw = min(B, a.W - c0);
-    for (int sub = tid; sub < a.subs; sub += 128) {
-        const int tile_r0 = by * B + sub * a.tile_rows;
-        const int r0 = max(tile_r0, a.row_begin);
-        const int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
-        if (r0 >= r1) continue;
-        bool covers = overflow;  // the generic kernel decides for itself
-        if (!overflow) {
-            const int wj_hi = H - r0, wj_lo = H - r1 + 1;  // world_j range of the tile's rows (alt:280)
-            for (int e = 0; e < n_entries; e++) {
-                const par_slot rec = sm.entries[e];
-                // alt:310-317 over the tile's pixel rectangle
-                covers |= (rec.px < c0 + tw) && (rec.px + rec.ex > c0) && (wj_hi > rec.py + rec.pz) &&
-                          (wj_lo <= rec.py + rec.ey + rec.pz + rec.ez);
-            }
-        }
-        if (covers) {
-            g.tileflag[a.set][col * g.subs + sub] = 1;
-            if (overflow) {
-                g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci * g.subs + sub;
-            } else {
-                g.fast_list[atomicAdd(&g.counters[PAR_CNT_FAST], 1)] = ci * g.subs + sub;
+            if (tid < n_entries) {
+                rec->entries[tid] = sm.entries[tid];
+                rec->ebz[tid] = sm.ebz[tid];
             }
         }
     }
+    if (overflow && tid == 0) g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;  // the exception
+    stamp(g, 0, 4);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// fill_kernel: background for every pixel of the row range whose screen column is not flagged. A pixel no
-// primitive covers is {127,127,127,0} (alt:281) times ambient (alt:735); its palette index is "none".
+// fill_kernel: background for every pixel of the row range. A pixel no primitive covers is {127,127,127,0}
+// (alt:281) times ambient (alt:735); its palette index is "none". The render kernels overwrite the tiles
+// primitives reach afterwards; the fill does not depend on the hash, so it runs beside the build.
 // Lane i of a wavefront owns pixels [8i, 8i+8) of a 512-pixel run: two 16-byte frame stores per lane, laid out so
 // that each store instruction of the wavefront covers 1 KiB contiguously, plus one 8-byte palette-index store.
-// Requires W % 8 == 0 and B % 4 == 0 (B % 8 == 0 for the palette plane); otherwise fill_generic_kernel runs.
+// Requires W % 8 == 0 and 16-byte aligned planes; otherwise fill_generic_kernel runs.
 // ------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void fill_kernel(par_grid_dev g, par_render_args a, uint32_t out_rgba) {
+__global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t out_rgba) {
     const int W = a.W;
     const int rows = a.row_end - a.row_begin;
     const int cpr = (W + 511) >> 9;  // 512-pixel chunks per row
@@ -497,32 +496,27 @@ __global__ __launch_bounds__(256) void fill_kernel(par_grid_dev g, par_render_ar
     for (int c = __builtin_amdgcn_readfirstlane((int)blockIdx.x * wpb + ((int)threadIdx.x >> 6)); c < n_chunks;
          c += (int)gridDim.x * wpb) {
         const int y = c / cpr, x0 = (c - y * cpr) << 9;
-        const int by = div_bin(y + a.row_begin, a.magic_b);
-        const int sub = (int)__umulhi((uint32_t)(y + a.row_begin - by * a.B), a.magic_tr);
         const size_t rowbase = (size_t)y * W;
         if (fb) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int x = x0 + h * 256 + lane * 4;
-                if (x < W && a.tileflag[(div_bin(x, a.magic_b) * g.gy + by) * g.subs + sub] == 0) {
+                if (x < W) {
                     *reinterpret_cast<uint4*>(fb + rowbase + x) = make_uint4(out_rgba, out_rgba, out_rgba, out_rgba);
                 }
             }
         }
         if (a.out.palidx) {
             const int x = x0 + lane * 8;
-            if (x < W && a.tileflag[(div_bin(x, a.magic_b) * g.gy + by) * g.subs + sub] == 0) {
-                *reinterpret_cast<uint2*>(a.out.palidx + rowbase + x) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-            }
+            if (x < W) *reinterpret_cast<uint2*>(a.out.palidx + rowbase + x) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         }
     }
 }
 
 // Any plane, any geometry: one pixel per thread (parity / debugging planes and odd view sizes).
-__global__ __launch_bounds__(256) void fill_generic_kernel(par_grid_dev g, par_render_args a, uint32_t out_rgba,
-                                                            int do_fb, int do_pal) {
-    const int W = a.W;
-    const long long npix = (long long)(a.row_end - a.row_begin) * W;
+__global__ __launch_bounds__(256) void fill_generic_kernel(par_render_args a, uint32_t out_rgba, int do_fb,
+                                                            int do_pal) {
+    const long long npix = (long long)(a.row_end - a.row_begin) * a.W;
     par_pixel px;
     px.normal = par_vec3{0.f, 0.f, 0.f};
     px.color.red = px.color.green = px.color.blue = (uint8_t)a.background;
@@ -530,10 +524,6 @@ __global__ __launch_bounds__(256) void fill_generic_kernel(par_grid_dev g, par_r
     px.y = 0; px.z = 0; px.entity_index = 0;
     for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < npix;
          p += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(p / W), x = (int)(p - (long long)y * W);
-        const int by = div_bin(y + a.row_begin, a.magic_b);
-        const int sub = (int)__umulhi((uint32_t)(y + a.row_begin - by * a.B), a.magic_tr);
-        if (a.tileflag[(div_bin(x, a.magic_b) * g.gy + by) * g.subs + sub] != 0) continue;
         if (do_fb && a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[p] = out_rgba;
         if (do_pal && a.out.palidx) a.out.palidx[p] = PAR_PALIDX_BACKGROUND;
         if (a.out.brightness) a.out.brightness[p] = a.ambient;
@@ -585,184 +575,228 @@ __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// render_fast_kernel: workgroups of 5 wavefronts (one pixel per lane) stride over the fast work list. Everything a
-// tile needs about its column arrives in ONE contiguous record (columns_kernel): 16 bytes per lane, one barrier,
-// then the pixels run out of LDS -- while the record of the workgroup's NEXT tile is already on its way.
+// render_fast_kernel: workgroups of 5 wavefronts stride over the occupied columns; for each they render the tiles
+// (B pixels wide, PAR_NT / B rows tall: 40 x 8, one pixel per lane) that some record of the column can cover.
+// Everything a column's tiles need arrives in ONE contiguous record (columns_kernel): 16 bytes per lane, one
+// barrier, then the pixels run out of LDS -- sprite 0's tables included -- while the record of the workgroup's
+// NEXT column is already on its way.
 // ------------------------------------------------------------------------------------------------------------
 
 struct FastShared {
-    par_colrec rec[2];                        // double buffered: the next tile's record is in flight
-    int32_t sprite_depth[PAR_SPRITE_TEXELS];  // depth table of sprite 0 (the hot lookup of the primary pass)
+    par_colrec rec[2];                         // double buffered: the next column's record is in flight
+    par_texel texinfo[PAR_SPRITE_TEXELS];      // sprite 0: normal + resolved palette colour per texel
+    int32_t sprite_depth[PAR_SPRITE_TEXELS];   // sprite 0: depth per texel (the hot lookup of the primary pass)
+    uint8_t sprite_color[PAR_SPRITE_TEXELS];   // sprite 0: palette index per texel
 };
 
 __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par_render_args a) {
     __shared__ FastShared sm;
     const int tid = threadIdx.x;
     const int W = a.W, H = a.H, B = a.B;
-    const int n_tiles = g.counters[PAR_CNT_FAST];
-    if ((int)blockIdx.x >= n_tiles) return;
-    const float ambient = a.ambient;
-    const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
-    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
-    for (int t = tid; t < PAR_SPRITE_TEXELS; t += PAR_NT) sm.sprite_depth[t] = a.sprites[0].depth[t];
-    const int py = (int)__umulhi((uint32_t)tid, a.magic_b);
-    const int px = tid - py * B;
-
+    stamp(g, 1, 0);
+    const int n_cols = min(g.counters[PAR_CNT_COLS], g.col_capacity);
+    if ((int)blockIdx.x >= n_cols) return;
     constexpr int NV = (int)(sizeof(par_colrec) / 16);  // 16-byte pieces of a record: one per lane
     static_assert(NV <= PAR_NT, "one record piece per lane");
     const int stride = (int)gridDim.x;
     int w = (int)blockIdx.x;
-    int tile_next = g.fast_list[w];
-    int tile_next2 = (w + stride < n_tiles) ? g.fast_list[w + stride] : -1;
     uint4 piece = make_uint4(0, 0, 0, 0);
-    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + tile_next / g.subs)[tid];
+    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + w)[tid];
+
+    const float ambient = a.ambient;
+    const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
+    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+    for (int t = tid; t < PAR_SPRITE_TEXELS; t += PAR_NT) {
+        sm.sprite_depth[t] = a.sprites[0].depth[t];
+        sm.texinfo[t] = a.texinfo[t];
+        sm.sprite_color[t] = (uint8_t)a.sprites[0].color[t];
+    }
+    stamp(g, 1, 1);
     for (int buf = 0;; buf ^= 1, w += stride) {
-        const int tile = tile_next;
         if (tid < NV) reinterpret_cast<uint4*>(&sm.rec[buf])[tid] = piece;
-        // One barrier per tile: the buffer written now was last read two tiles ago, and every lane has passed the
-        // previous tile's barrier since.
+        // One barrier per column: the buffer written now was last read two columns ago, and every lane has passed
+        // the previous column's barrier since.
         __syncthreads();
-        tile_next = tile_next2;
-        if (tile_next >= 0) {  // prefetch: the record of the next tile, and the list entry after it
-            if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + tile_next / g.subs)[tid];
-            tile_next2 = (w + 2 * stride < n_tiles) ? g.fast_list[w + 2 * stride] : -1;
-        }
+        if (w == (int)blockIdx.x) stamp(g, 1, 2);
+        const bool has_next = w + stride < n_cols;
+        if (has_next && tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + w + stride)[tid];
         const par_colrec& rec_ = sm.rec[buf];
-        const int ci = tile / g.subs, sub = tile - ci * g.subs;
+        const int n_entries = (rec_.overflow || (a.flags & (1u << 24))) ? 0 : rec_.n_entries;  // bit 24: ablation
+        const int n_nb = rec_.n_nb;
         const int col_id = rec_.col;
         const int bx = col_id / g.gy, by = col_id - bx * g.gy;
-        const int tile_r0 = by * B + sub * a.tile_rows;
-        const int r0 = max(tile_r0, a.row_begin);
-        const int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
         const int c0 = bx * B;
         const int tw = min(B, W - c0);
-        const int col = c0 + px, row = tile_r0 + py;
-        const bool valid = (px < tw) && (row >= r0) && (row < r1);
-        const int n_nb = (a.flags & (1u << 24)) ? 0 : rec_.n_nb;  // bit 24: ablation (timing only), no primary pass
+        const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
 
-        // ---- primary ray, alt:271-397 --------------------------------------------------------------------------
-        bool hit = false;
-        int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;  // background texel: y = z = 0, entity_index 0 (alt:281)
-        {
-            const int i = col;
-            const int world_j = (int)(int16_t)(H - row);  // alt:280
-            int adjacent = 0;                             // alt:282
-            int closest = INT_MIN;                        // alt:289
-            int prev_bz = -2;
-            bool done = !valid;
-            int w_ybase = 0, w_pz = 0, w_d = 0;
-            for (int n = 0; n < n_nb; n++) {
-                if (__all(done)) break;  // wavefront early-out (alt:372-374)
-                const par_colrec_nb nb = rec_.nb[n];
-                if (!done) {
-                    if (nb.bz != prev_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
-                    prev_bz = nb.bz;
-                    bool hit_in_bin = false;
-                    for (int s = 0; s < nb.cnt; s++) {
-                        const par_slot rec = rec_.entries[nb.off + s];
-                        const int top = rec.py + rec.ey + rec.pz + rec.ez;
-                        if (i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
-                            const int sprite_row = top - world_j;                         // alt:324-326
-                            const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
-                            const int sid = a.sprite_ids ? a.sprite_ids[rec.entity] : 0;  // alt:321-322
-                            const int d = (sid == 0) ? sm.sprite_depth[t] : a.sprites[sid].depth[t];
-                            const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
-                            if (closest >= depth) continue;                               // alt:344-346
+        // Pixels are visited entry by entry: the screen rectangle of entry `own` inside this column, row-major, one
+        // pixel per lane. A pixel several entries cover belongs to the FIRST of them in list order, so every
+        // covered pixel is rendered exactly once and the lanes of a pass are (nearly) all covered pixels; what no
+        // entry covers keeps the background fill_kernel wrote.
+        for (int own = 0; own < n_entries; own++) {  // uniform
+            int rx0, rw, ry0, rh;
+            {
+                const par_slot r = rec_.entries[own];
+                rx0 = max((int)r.px, c0);
+                rw = min(r.px + r.ex, c0 + tw) - rx0;
+                // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
+                ry0 = max(H - (r.py + r.ey + r.pz + r.ez), rows_lo);
+                rh = min(H - (r.py + r.pz), rows_hi) - ry0;
+            }
+            rx0 = __builtin_amdgcn_readfirstlane(rx0);
+            rw = __builtin_amdgcn_readfirstlane(rw);
+            ry0 = __builtin_amdgcn_readfirstlane(ry0);
+            rh = __builtin_amdgcn_readfirstlane(rh);
+            if (rw <= 0 || rh <= 0) continue;
+            // floor(p / rw) == __umulhi(p, magic_w) for p * rw < 2^32; a 1-pixel-wide rectangle has no such multiplier
+            const uint32_t magic_w = (uint32_t)(0xFFFFFFFFu / (uint32_t)rw) + 1u;
+            const int area = rw * rh;
+            for (int base = 0; base < area; base += PAR_NT) {
+            const int pidx = base + tid;
+            const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
+            const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
+            bool valid = pidx < area;
+            if (!__any(valid)) continue;  // this wavefront's lanes all lie beyond the rectangle
+
+            // ---- primary ray, alt:271-397: the column's entries front to back as one flat list -----------------
+            bool hit = false;
+            int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;
+            {
+                const int i = col;
+                const int world_j = (int)(int16_t)(H - row);  // alt:280
+                int adjacent = 0;                             // alt:282
+                int closest = INT_MIN;                        // alt:289
+                int cur_bz = -2;
+                int first_cover = n_entries;                  // first entry whose test (alt:310-317) passes
+                bool hit_in_bin = false;
+                bool done = !valid;
+                int w_ybase = 0, w_pz = 0, w_d = 0;
+                for (int e = 0; e < n_entries; e++) {
+                    const int bz = rec_.ebz[e];
+                    const par_slot rec = rec_.entries[e];
+                    if (bz != cur_bz) {  // the previous bin is complete
+                        adjacent += hit_in_bin ? 1 : 0;      // alt:368
+                        if (adjacent >= 2) done = true;      // alt:372-374
+                        if (bz != cur_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
+                        cur_bz = bz;
+                        hit_in_bin = false;
+                    }
+                    // a lane whose pixel an earlier entry owns has nothing to do in this pass
+                    if (first_cover < own) done = true;
+                    if (__all(done)) break;  // wavefront early-out
+                    const int top = rec.py + rec.ey + rec.pz + rec.ez;
+                    if (!done && i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
+                        first_cover = min(first_cover, e);
+                        const int sprite_row = top - world_j;                         // alt:324-326
+                        const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
+                        const int sid = a.sprite_ids ? a.sprite_ids[rec.entity] : 0;  // alt:321-322
+                        const int d = (sid == 0) ? sm.sprite_depth[t] : a.sprites[sid].depth[t];
+                        const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
+                        if (closest < depth) {                                        // alt:344-346
                             closest = depth;
-                            w_ybase = rec.py + rec.ey + rec.ez - sprite_row;              // alt:356-359
-                            w_pz = rec.pz;                                                // alt:360-361
+                            w_ybase = rec.py + rec.ey + rec.ez - sprite_row;          // alt:356-359
+                            w_pz = rec.pz;                                            // alt:360-361
                             w_d = d;
-                            p_entity = rec.entity;                                        // alt:363
+                            p_entity = rec.entity;                                    // alt:363
                             p_tex = sid * PAR_SPRITE_TEXELS + t;
                             hit = true;
-                            hit_in_bin = true;                                            // alt:365
+                            hit_in_bin = true;                                        // alt:365
                         }
                     }
-                    adjacent += hit_in_bin ? 1 : 0;  // alt:368
-                    if (adjacent >= 2) done = true;  // alt:372-374
+                }
+                valid = valid && first_cover == own;  // this pass renders the pixels entry `own` is the first to cover
+                hit = hit && valid;
+                if (hit) {
+                    p_y = w_ybase - w_d;
+                    p_z = w_pz + w_d;
                 }
             }
-            if (hit) {
-                p_y = w_ybase - w_d;
-                p_z = w_pz + w_d;
-            }
-        }
 
-        // ---- shading, alt:704-758 ------------------------------------------------------------------------------
-        float nx = 0.f, ny = 0.f, nz = 0.f;
-        uint32_t rgba = bg_rgba;
-        int pal_index = PAR_PALIDX_BACKGROUND;
-        float bright = ambient;  // background: min(1, max(0, 0 * t) + ambient) either way (SURVEY a-6), ray skipped
-        if (hit && !(a.flags & (1u << 26))) {  // bit 26: ablation (timing experiments only), no shading
-            const par_texel ti = a.texinfo[p_tex];  // normal (alt:349-350) + resolved palette colour (alt:352-354)
-            nx = ti.nx; ny = ti.ny; nz = ti.nz;
-            rgba = ti.rgba;
-            if (a.out.palidx) {
-                const int sid = p_tex / PAR_SPRITE_TEXELS;
-                pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
-            }
-            const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
-            // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
-            const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
-            const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
-            const float tx = dx / len, ty = dy / len, tz = dz / len;
-            const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
-            const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
-            const float diffuse = std_max(0.f, dot);                           // alt:745
-            const float b_lit = std_min(1.f, diffuse + ambient);               // alt:758
-            const int sy = div_bin(H - wy - wz, a.magic_b);                    // alt:725-726
-            const int sz = div_bin(wz, a.magic_b);                             // alt:727
-            const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
-            // shadow ray, alt:738-742: the walk from the start bin was done by columns_kernel
-            bool lit = true;
-            int wi = -1;
-            if (sy == by) {
-                for (int n = 0; n < n_nb; n++) {
-                    if (rec_.nb[n].bz == sz) wi = n;
-                }
-            }
-            if (wi >= 0) {
-                const int woff = rec_.nb[wi].woff, wcnt = rec_.nb[wi].wcnt;
-                for (int r = 0; r < wcnt; r++) {
-                    const par_slot rec = rec_.walk[woff + r];
-                    if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
-                        lit = false;
-                        break;
+            // ---- shading, alt:704-758 --------------------------------------------------------------------------
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            uint32_t rgba = bg_rgba;
+            int pal_index = PAR_PALIDX_BACKGROUND;
+            float bright = ambient;  // background: min(1, max(0, 0*t) + ambient) either way (SURVEY a-6); ray skipped
+            if (hit && !(a.flags & (1u << 26))) {  // bit 26: ablation (timing experiments only), no shading
+                // normal (alt:349-350) + resolved palette colour (alt:352-354)
+                const par_texel ti = (p_tex < PAR_SPRITE_TEXELS) ? sm.texinfo[p_tex] : a.texinfo[p_tex];
+                nx = ti.nx; ny = ti.ny; nz = ti.nz;
+                rgba = ti.rgba;
+                if (a.out.palidx) {
+                    if (p_tex < PAR_SPRITE_TEXELS) {
+                        pal_index = sm.sprite_color[p_tex];
+                    } else {
+                        const int sid = p_tex / PAR_SPRITE_TEXELS;
+                        pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
                     }
                 }
-            } else {
-                lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y, inv_z);
+                const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
+                // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
+                const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
+                const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
+                const float tx = dx / len, ty = dy / len, tz = dz / len;
+                const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
+                const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
+                const float diffuse = std_max(0.f, dot);                           // alt:745
+                const float b_lit = std_min(1.f, diffuse + ambient);               // alt:758
+                const int sy = div_bin(H - wy - wz, a.magic_b);                    // alt:725-726
+                const int sz = div_bin(wz, a.magic_b);                             // alt:727
+                const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
+                // shadow ray, alt:738-742: the walk from the start bin was done by columns_kernel
+                bool lit = true;
+                int wi = -1;
+                if (sy == by) {
+                    for (int n = 0; n < n_nb; n++) {
+                        if (rec_.nb[n].bz == sz) wi = n;
+                    }
+                }
+                if (wi >= 0) {
+                    const int woff = rec_.nb[wi].woff, wcnt = rec_.nb[wi].wcnt;
+                    for (int r = 0; r < wcnt; r++) {
+                        const par_slot rec = rec_.walk[woff + r];
+                        if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
+                            lit = false;
+                            break;
+                        }
+                    }
+                } else {
+                    lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y,
+                                           inv_z);
+                }
+                bright = lit ? b_lit : ambient;
             }
-            bright = lit ? b_lit : ambient;
-        }
-        if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
-            const unsigned long long m = __ballot(valid && hit);
-            if ((tid & 63) == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
-        }
+            if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
+                const unsigned long long m = __ballot(valid && hit);
+                if ((tid & 63) == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
+            }
 
-        // ---- quantise + store, alt:735, 757-758 ----------------------------------------------------------------
-        if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
-            asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
-        } else if (valid) {
-            const size_t o = (size_t)(row - a.row_begin) * W + col;
-            if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
-            if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
-            if (a.out.brightness) a.out.brightness[o] = bright;
-            if (a.out.gbuf) {
-                par_pixel pxl;
-                pxl.normal = par_vec3{nx, ny, nz};
-                pxl.color.red = (uint8_t)(rgba & 0xFF);
-                pxl.color.green = (uint8_t)((rgba >> 8) & 0xFF);
-                pxl.color.blue = (uint8_t)((rgba >> 16) & 0xFF);
-                pxl.color.alpha = (uint8_t)(rgba >> 24);
-                pxl.y = p_y;
-                pxl.z = p_z;
-                pxl.entity_index = p_entity;
-                a.out.gbuf[o] = pxl;
+            // ---- quantise + store, alt:735, 757-758 ------------------------------------------------------------
+            if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
+                asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
+            } else if (valid) {
+                const size_t o = (size_t)(row - a.row_begin) * W + col;
+                if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
+                if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
+                if (a.out.brightness) a.out.brightness[o] = bright;
+                if (a.out.gbuf) {
+                    par_pixel pxl;
+                    pxl.normal = par_vec3{nx, ny, nz};
+                    pxl.color.red = (uint8_t)(rgba & 0xFF);
+                    pxl.color.green = (uint8_t)((rgba >> 8) & 0xFF);
+                    pxl.color.blue = (uint8_t)((rgba >> 16) & 0xFF);
+                    pxl.color.alpha = (uint8_t)(rgba >> 24);
+                    pxl.y = p_y;
+                    pxl.z = p_z;
+                    pxl.entity_index = p_entity;
+                    a.out.gbuf[o] = pxl;
+                }
             }
-        }
-        if (tile_next < 0) break;
+            }  // passes over the rectangle
+        }      // entries
+        if (w == (int)blockIdx.x) stamp(g, 1, 3);
+        if (!has_next) break;
     }
+    stamp(g, 1, 4);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1118,11 +1152,11 @@ __global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, pa
             __syncthreads();
         }
     } else {
-        const int n_tiles = g.counters[PAR_CNT_SLOW];
-        for (int w = (int)blockIdx.x; w < n_tiles; w += (int)gridDim.x) {
-            const int tile = g.slow_list[w];
-            const int ci = tile / g.subs, sub = tile - ci * g.subs;
-            const int col = g.col_list[ci];
+        // the columns whose record overflowed: every tile of theirs in the row range
+        const int n_slow = g.counters[PAR_CNT_SLOW];
+        for (int w = (int)blockIdx.x; w < n_slow * a.subs; w += (int)gridDim.x) {
+            const int k = w / a.subs, sub = w - k * a.subs;
+            const int col = g.col_list[g.slow_list[k]];
             const int bx = col / g.gy, by = col - (col / g.gy) * g.gy;
             render_tile_generic(g, a, sm, bx, by, sub);
             __syncthreads();
@@ -1172,8 +1206,8 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
     const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);
     const uint32_t out_rgba = ch | (ch << 8) | (ch << 16);
     const int64_t npix = (int64_t)(a.row_end - a.row_begin) * a.W;
-    const bool fb_fast = a.out.fb && (a.W % 8 == 0) && (a.B % 4 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
-    const bool pal_fast = a.out.palidx && (a.W % 8 == 0) && (a.B % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0);
+    const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
+    const bool pal_fast = a.out.palidx && (a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0);
     if (fb_fast || pal_fast) {
         par_render_args f = a;
         if (!fb_fast) f.out.fb = nullptr;
@@ -1181,7 +1215,7 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
         const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
         int64_t blocks = (chunks + 3) / 4;  // 4 wavefronts per block, one 512-pixel chunk each per iteration
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, f, out_rgba);
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f, out_rgba);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
@@ -1189,36 +1223,31 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
     if (need_generic) {
         int64_t blocks = (npix + 255) / 256;
         if (blocks > 16384) blocks = 16384;
-        hipLaunchKernelGGL(fill_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a, out_rgba,
+        hipLaunchKernelGGL(fill_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, out_rgba,
                            fb_fast ? 0 : 1, pal_fast ? 0 : 1);
         return hipGetLastError();
     }
     return hipSuccess;
 }
 
-hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t tile_bound, bool graph_mode,
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                              hipStream_t stream) {
-    const int64_t tiles_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1) * a.subs;
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    const int64_t tiles_in_range = cols_in_range * a.subs;
     if (tiles_in_range <= 0 || tiles_in_range > 0x7FFFFFFF) return hipErrorInvalidValue;
     if (a.dense) {
         hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)tiles_in_range), dim3(PAR_NT), 0, stream, g, a);
         return hipGetLastError();
     }
-    int64_t bound = tile_bound < tiles_in_range ? tile_bound : tiles_in_range;
+    const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound <= 0) return hipSuccess;
-    // The work lists live on the device. Outside a graph the host knows a tight bound (the tiles the boxes'
-    // screen rectangles can touch): one workgroup per listed tile, the few extra ones exit at once. A captured
-    // graph must hold for later frames too: cap the grid and let the workgroups stride over the list.
-    // 5 resident workgroups per CU (70 VGPRs -> 7 wavefronts per SIMD): more would only queue behind them, and a
-    // workgroup that takes several tiles overlaps the next record's load with the current tile's pixels
+    // 5 resident workgroups per CU (7 wavefronts per SIMD): more would only queue behind them, and a workgroup
+    // that takes several columns overlaps the next record's load with the current column's pixels
     const int64_t cap = (int64_t)256 * 5;
-    const int64_t fast_blocks = bound > cap ? cap : bound;
-    (void)graph_mode;
-    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)fast_blocks), dim3(PAR_NT), 0, stream, g, a);
+    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)(bound > cap ? cap : bound)), dim3(PAR_NT), 0, stream, g, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // overflowed columns are the exception: a small strided grid
-    const int64_t slow_blocks = bound < 512 ? bound : 512;
-    hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)slow_blocks), dim3(PAR_NT), 0, stream, g, a);
+    hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)(bound < 256 ? bound : 256)), dim3(PAR_NT), 0, stream, g, a);
     return hipGetLastError();
 }
