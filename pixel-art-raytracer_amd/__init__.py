@@ -9,7 +9,9 @@ The package directory name carries a hyphen, so import it with
     par = importlib.import_module("pixel-art-raytracer_amd")
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -45,6 +47,25 @@ class ParError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process. PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7)
+    and link it by FILE name; our library links the SONAME. If ours is loaded first the dynamic loader brings in
+    /opt/rocm's copy and a later `import torch` adds a second runtime that sees no device. Loading torch's copy
+    first (when torch is installed and not yet imported) makes both resolve to the same one; with torch already
+    imported, or absent, there is nothing to do."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libpar_raytracer.so (built in-tree by __graft_entry__.build() / csrc/Makefile). No fallback."""
     global _lib
@@ -52,6 +73,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C pixel-art-raytracer_amd/csrc` "
                               "(or __graft_entry__.build()). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         vp, i32 = C.c_void_p, C.c_int
         L.par_status_string.restype = C.c_char_p

@@ -295,6 +295,7 @@ struct ColShared {
     int32_t wsum[2];
     int32_t n_walk;
     int32_t overflow;
+    int32_t tile_mode;
 };
 
 __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render_args a) {
@@ -452,6 +453,23 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
     const bool overflow = sm.overflow != 0;
     stamp(g, 0, 3);
 
+    // ---- how the render kernel should visit the column's pixels: entry rectangle by entry rectangle when they
+    // cover little of it (the lanes of a pass are then nearly all covered pixels), otherwise whole tiles -----------
+    if (tid == 0) {
+        const int c0 = bx * a.B, tw = min(a.B, a.W - c0);
+        const int rows_lo = max(by * a.B, a.row_begin), rows_hi = min(min((by + 1) * a.B, a.H), a.row_end);
+        int area = 0;
+        for (int e = 0; e < (overflow ? 0 : n_entries); e++) {
+            const par_slot r = sm.entries[e];
+            const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
+            const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
+            // every pass costs whole wavefronts: count the rectangle in units of the workgroup
+            if (w > 0 && h > 0) area += ((w * h + PAR_NT - 1) / PAR_NT) * PAR_NT;
+        }
+        sm.tile_mode = (area >= tw * max(rows_hi - rows_lo, 0)) ? 1 : 0;
+    }
+    __syncthreads();
+
     // ---- C: the record ----------------------------------------------------------------------------------------
     if (ci < g.col_capacity) {
         par_colrec* rec = g.colrec + ci;
@@ -461,7 +479,8 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
             rec->n_walk = (int16_t)sm.n_walk;
             rec->overflow = overflow ? 1 : 0;
             rec->col = col;
-            rec->cover[0] = rec->cover[1] = rec->cover[2] = 0;
+            rec->cover[0] = sm.tile_mode;
+            rec->cover[1] = rec->cover[2] = 0;
         }
         if (!overflow) {
             if (tid < n_nb) rec->nb[tid] = sm.nb[tid];
@@ -595,13 +614,17 @@ __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par
     const int W = a.W, H = a.H, B = a.B;
     stamp(g, 1, 0);
     const int n_cols = min(g.counters[PAR_CNT_COLS], g.col_capacity);
-    if ((int)blockIdx.x >= n_cols) return;
+    if (n_cols <= 0 || (int)blockIdx.x >= n_cols * max(1, min(8, (int)gridDim.x / n_cols))) return;
     constexpr int NV = (int)(sizeof(par_colrec) / 16);  // 16-byte pieces of a record: one per lane
     static_assert(NV <= PAR_NT, "one record piece per lane");
+    // A column is split into `parts` work items when there are fewer columns than resident workgroups (small
+    // frames), so that the whole chip still has something to do.
     const int stride = (int)gridDim.x;
+    const int parts = max(1, min(8, stride / n_cols));
+    const int n_items = n_cols * parts;
     int w = (int)blockIdx.x;
     uint4 piece = make_uint4(0, 0, 0, 0);
-    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + w)[tid];
+    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + w / parts)[tid];
 
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
@@ -614,12 +637,13 @@ __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par
     stamp(g, 1, 1);
     for (int buf = 0;; buf ^= 1, w += stride) {
         if (tid < NV) reinterpret_cast<uint4*>(&sm.rec[buf])[tid] = piece;
-        // One barrier per column: the buffer written now was last read two columns ago, and every lane has passed
-        // the previous column's barrier since.
+        // One barrier per work item: the buffer written now was last read two items ago, and every lane has passed
+        // the previous item's barrier since.
         __syncthreads();
         if (w == (int)blockIdx.x) stamp(g, 1, 2);
-        const bool has_next = w + stride < n_cols;
-        if (has_next && tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + w + stride)[tid];
+        const bool has_next = w + stride < n_items;
+        if (has_next && tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + (w + stride) / parts)[tid];
+        const int part = w - (w / parts) * parts;
         const par_colrec& rec_ = sm.rec[buf];
         const int n_entries = (rec_.overflow || (a.flags & (1u << 24))) ? 0 : rec_.n_entries;  // bit 24: ablation
         const int n_nb = rec_.n_nb;
@@ -629,14 +653,26 @@ __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par
         const int tw = min(B, W - c0);
         const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
 
-        // Pixels are visited entry by entry: the screen rectangle of entry `own` inside this column, row-major, one
-        // pixel per lane. A pixel several entries cover belongs to the FIRST of them in list order, so every
-        // covered pixel is rendered exactly once and the lanes of a pass are (nearly) all covered pixels; what no
-        // entry covers keeps the background fill_kernel wrote.
-        for (int own = 0; own < n_entries; own++) {  // uniform
+        // How the column's pixels are visited (columns_kernel decides per column):
+        //  - entry by entry: the screen rectangle of entry `own` inside this column, row-major, one pixel per
+        //    lane. A pixel several entries cover belongs to the FIRST of them in list order, so every covered
+        //    pixel is rendered exactly once and the lanes of a pass are (nearly) all covered pixels; what no entry
+        //    covers keeps the background fill_kernel wrote;
+        //  - as whole tiles (own = -1) when the rectangles would add up to more than the column itself.
+        const bool tile_mode = rec_.cover[0] != 0;
+        const int n_pass = tile_mode ? 1 : n_entries;
+        for (int q = tile_mode ? 0 : part; q < n_pass; q += tile_mode ? 1 : parts) {  // uniform
+            const int own = tile_mode ? -1 : q;
             int rx0, rw, ry0, rh;
-            {
-                const par_slot r = rec_.entries[own];
+            if (tile_mode) {
+                // this work item's share of the column's rows
+                const int rows = rows_hi - rows_lo, share = (rows + parts - 1) / parts;
+                rx0 = c0;
+                rw = tw;
+                ry0 = rows_lo + part * share;
+                rh = min(share, rows_hi - ry0);
+            } else {
+                const par_slot r = rec_.entries[q];
                 rx0 = max((int)r.px, c0);
                 rw = min(r.px + r.ex, c0 + tw) - rx0;
                 // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
@@ -682,7 +718,7 @@ __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par
                         hit_in_bin = false;
                     }
                     // a lane whose pixel an earlier entry owns has nothing to do in this pass
-                    if (first_cover < own) done = true;
+                    if (first_cover < own) done = true;  // (never in tile mode: own = -1)
                     if (__all(done)) break;  // wavefront early-out
                     const int top = rec.py + rec.ey + rec.pz + rec.ez;
                     if (!done && i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
@@ -704,7 +740,8 @@ __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par
                         }
                     }
                 }
-                valid = valid && first_cover == own;  // this pass renders the pixels entry `own` is the first to cover
+                // an entry pass renders the pixels entry `own` is the first to cover; a tile pass renders them all
+                valid = valid && (own < 0 || first_cover == own);
                 hit = hit && valid;
                 if (hit) {
                     p_y = w_ybase - w_d;
@@ -1244,7 +1281,8 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     // 5 resident workgroups per CU (7 wavefronts per SIMD): more would only queue behind them, and a workgroup
     // that takes several columns overlaps the next record's load with the current column's pixels
     const int64_t cap = (int64_t)256 * 5;
-    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)(bound > cap ? cap : bound)), dim3(PAR_NT), 0, stream, g, a);
+    // (a column is split into up to 8 work items when there are fewer columns than resident workgroups)
+    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)(bound * 8 > cap ? cap : bound * 8)), dim3(PAR_NT), 0, stream, g, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // overflowed columns are the exception: a small strided grid

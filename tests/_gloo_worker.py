@@ -1,0 +1,51 @@
+"""Worker for test_sharding_gloo.py: one rank of a world_size-N gloo job (CPU). Each rank produces its row block of
+the frame with the CPU oracle (standing in for the GPU it does not have) and the blocks are assembled with the same
+FrameGather the GPU bench uses."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    height = int(sys.argv[1])
+    width = int(sys.argv[2])
+    out_path = sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    par = importlib.import_module("pixel-art-raytracer_amd")
+    sharding = importlib.import_module("pixel-art-raytracer_amd.sharding")
+    from oracle.oracle import Oracle
+    T = par.types
+    o = Oracle()
+    params = T.default_params(width, height, height)
+    aabbs, light = par.scene_synthetic(200, width, height, height, 77)
+    sprite = par.tile_floor()
+    r0, r1 = sharding.row_block(rank, world, height)
+    grid = o.bin(params, aabbs)
+    gbuf, _ = o.primary(params, grid, sprite, rows=(r0, r1))
+    fb, _, _ = o.shade(params, grid, gbuf, light, rows=(r0, r1))
+    g = sharding.FrameGather(height, width * 4, torch.uint8, torch.device("cpu"), world, rank)
+    block = g.block_buffer(torch.uint8, torch.device("cpu"))
+    mine = torch.from_numpy(fb[r0 * width:r1 * width].view(np.uint8).copy())
+    block[:mine.numel()] = mine
+    work = g.gather(block, async_op=True)
+    work.wait()
+    g.unpack()
+    if rank == 0:
+        full = o.render(params, aabbs, sprite, light, planes=("fb",))["fb"].view(np.uint8)
+        ok = bool(np.array_equal(g.frame.numpy(), full))
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""GPU parity, second batch: hipGraph replay with moving primitives (BASELINE config 5), the paths that leave the
+fast kernel (column records that overflow, shadow rays that start in unoccupied bins), mouse pick."""
+import numpy as np
+import pytest
+
+from test_gpu_parity import ALL, assert_planes_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sprite(par):
+    return par.tile_floor()
+
+
+def test_graph_replay_with_moving_primitives(par, oracle, sprite, T):
+    import torch
+    w, h, l = 640, 400, 400
+    params = T.default_params(w, h, l)
+    n = 256
+    aabbs, light = par.scene_synthetic(n, w, h, l, 31)
+    rng = np.random.default_rng(5)
+    vel = rng.choice([-5, 0, 5], size=(n, 3))  # the reference's step size (alt:643-678)
+    fb = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    pal = torch.zeros(w * h, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        r.graph_capture({"fb": fb.data_ptr(), "palidx": pal.data_ptr()}, stream=stream.cuda_stream)
+        for f in range(12):
+            if f:
+                aabbs["px"] += vel[:, 0].astype(np.int16)
+                aabbs["py"] += vel[:, 1].astype(np.int16)
+                aabbs["pz"] += vel[:, 2].astype(np.int16)
+                light["x"] -= 5
+                r.graph_stage(aabbs, 0, light)
+            r.graph_launch(stream.cuda_stream)
+            stream.synchronize()
+            exp = oracle.render(params, aabbs, sprite, light, planes=("fb", "palidx"))
+            assert np.array_equal(fb.cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
+            assert np.array_equal(pal.cpu().numpy(), exp["palidx"]), f"frame {f}"
+
+
+def test_update_aabbs_between_frames(par, oracle, sprite, T):
+    w, h, l = 480, 320, 320
+    params = T.default_params(w, h, l)
+    aabbs, light = par.scene_synthetic(300, w, h, l, 8)
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        for f in range(6):
+            aabbs["px"][:50] += 5
+            aabbs["pz"][10:60] -= 5
+            r.update_aabbs(aabbs[:60], 0)
+            out = r.render(ALL)
+            assert_planes_equal(out, oracle.render(params, aabbs, sprite, light), ALL, f"frame {f}")
+
+
+def test_overflowing_columns_take_the_generic_kernel(par, oracle, sprite, T):
+    # hundreds of boxes stacked into a few columns: more slot records / occluders than a column record holds
+    w, h, l = 480, 320, 320
+    params = T.default_params(w, h, l)
+    rng = np.random.default_rng(2)
+    rows = [(int(rng.integers(200, 260)), int(rng.integers(0, 40)), int(z), 20, 20, 20)
+            for z in rng.integers(0, 300, 500)]
+    rows += [(i * 20, 0, j * 20, 20, 20, 20) for i in range(24) for j in range(16)]
+    aabbs = T.make_aabbs(rows)
+    for lpos in [(300, 160, 80), (230, 60, 10)]:
+        light = T.make_light(*lpos)
+        exp = oracle.render(params, aabbs, sprite, light)
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            fast = r.render(("fb", "palidx", "brightness", "gbuf"))
+            assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"overflow {lpos}")
+            assert_planes_equal(r.render(ALL), exp, ALL, f"overflow dense {lpos}")
+
+
+def test_shadow_rays_from_unoccupied_bins(par, oracle, T):
+    # sprite depths far outside the box (and negative world z) put the ray's start bin where no primitive is:
+    # the fast kernel then walks per lane (trace_hash_for_light as written)
+    w, h, l = 480, 320, 320
+    params = T.default_params(w, h, l)
+    sprite = par.tile_floor()
+    sprite["depth"][0][:400] = 95      # top face "floats" two bins deeper
+    sprite["depth"][0][400:] = -70     # front face two bins nearer (negative world z near the view front)
+    aabbs, light = par.scene_synthetic(250, w, h, l, 13)
+    aabbs["pz"][:40] = -20
+    exp = oracle.render(params, aabbs, sprite, light)
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        fast = r.render(("fb", "palidx", "brightness", "gbuf"))
+        assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), "exotic depth")
+        assert_planes_equal(r.render(ALL), exp, ALL, "exotic depth dense")
+
+
+def test_pick_and_stats(par, oracle, sprite, T):
+    params = T.default_params()
+    aabbs, light = par.scene_synthetic(200, 480, 320, 320, 4)
+    exp = oracle.render(params, aabbs, sprite, light, planes=("gbuf",))["gbuf"].reshape(320, 480)
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        for (x, y) in [(0, 0), (240, 160), (479, 319), (100, 37)]:
+            assert r.pick(x, y).tobytes() == exp[y, x].tobytes()  # `mouse_pixel`, alt:380-382
+        r.render(("fb",))
+        st = r.stats()
+        assert st.entities == 200 and st.bin_insertions > 0 and st.occupied_columns > 0
+
+
+def test_other_bin_sizes_and_palettes(par, oracle, sprite, T):
+    for bin_size, (w, h, l) in [(32, (512, 384, 256)), (64, (400, 300, 300)), (20, (320, 200, 200))]:
+        params = T.default_params(w, h, l, bin_size)
+        params.ambient = 0.4
+        params.background = 90
+        params.palette_size = 4
+        for i, c in enumerate([(10, 200, 30, 7), (255, 0, 0, 255), (1, 2, 3, 4), (90, 90, 250, 0)]):
+            params.palette[i] = T.Color(*c)
+        aabbs, light = par.scene_synthetic(220, w, h, l, bin_size)
+        exp = oracle.render(params, aabbs, sprite, light)
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            assert_planes_equal(r.render(ALL), exp, ALL, f"bin {bin_size} dense")
+            fast = r.render(("fb", "palidx", "brightness", "gbuf"))
+            assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"bin {bin_size}")
