@@ -66,8 +66,8 @@ def cpu_baseline(par, T, params, aabbs, light, sprite, rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -135,12 +135,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (untimed)
-    for i in range(args.warmup):
+    # correctness of what is about to be timed (before the warm-up, so that the GPU does not idle between warm-up
+    # and the timed region): rank 0 renders the whole frame alone and compares
+    for i in range(2):
         step(i)
     drain()
-
-    # correctness of what is being timed: rank 0 renders the whole frame alone and compares
     verified = None
     if rank == 0:
         full = r.render(("fb", "palidx"))
@@ -150,6 +149,12 @@ def main():
             verified = bool(np.array_equal(fb[0].cpu().numpy(), full["fb"].view(np.uint8)) and
                             np.array_equal(pal[0].cpu().numpy(), full["palidx"]))
         hit_pixels = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
+    barrier()
+
+    # warm-up (untimed)
+    for i in range(args.warmup):
+        step(i)
+    drain()
 
     # timed region: exactly K steps
     barrier()
@@ -198,45 +203,45 @@ def main():
         avg = {k: float(np.mean(v)) for k, v in ms.items()}
         ncols = int(r.stats().occupied_columns)
         gx, gy, gz = params.grid_dims()
-        # Algorithmic bytes: 2.5 B per nominal ray (4 B RGBA + 1 B palette index per pixel, two rays per
-        # pixel). The frame's pixels are written by two kernels: render_tiles_kernel owns the pixels of the screen
-        # columns that show a primitive (one column = one 40x40 bin footprint), fill_kernel the rest.
-        B_ = params.bin_size
-        px_render = min(int(ncols) * B_ * B_, W * H)  # edge columns are narrower: a slight over-count
+        # Algorithmic bytes: 2.5 B per nominal ray = 5 B per pixel (4 B RGBA8 + 1 B palette index; two
+        # rays per pixel). fill_kernel writes every pixel of the frame once (5 B x W x H); render_fast_kernel then
+        # writes the pixels primitives cover (5 B x covered pixels) - the only bytes that kernel has to move.
         bytes_frame = 2.5 * 2.0 * W * H
-        bytes_render = 5.0 * px_render
-        bytes_fill = bytes_frame - bytes_render
-        dominant = "render_tiles_kernel" if avg["render"] >= avg["fill"] else "fill_kernel"
-        dom_bytes = bytes_render if dominant == "render_tiles_kernel" else bytes_fill
-        dom_ms = avg["render"] if dominant == "render_tiles_kernel" else avg["fill"]
+        bytes_render = 5.0 * hit_pixels
+        kernels = {"render_fast_kernel": (avg["render"], bytes_render), "fill_kernel": (avg["fill"], bytes_frame)}
+        dominant = max(kernels, key=lambda k: kernels[k][0])
+        dom_ms, dom_bytes = kernels[dominant]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = json.load(f).get(dominant + "_hbm_bytes_per_launch")
-        frame_ms = avg["bin"] + avg["fill"] + avg["render"]
+        serial_ms = avg["bin"] + avg["fill"] + avg["render"]
         out["roofline"] = {
             "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(dom_bytes), "avg_kernel_ms": round(dom_ms, 5),
-            "timing": "hipEvent pairs around the kernel on its launch stream, mean of 30 frames",
-            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); this kernel writes "
-                        f"{px_render if dominant == 'render_tiles_kernel' else W * H - px_render} of {W * H} pixels",
-            "kernels_ms": {"hash_build_and_walk": round(avg["bin"], 5), "fill_kernel": round(avg["fill"], 5),
-                           "render_tiles_kernel": round(avg["render"], 5)},
-            "fill_kernel": {"achieved": round(bytes_fill / (avg["fill"] * 1e-3) / 1e9, 1),
-                            "frac": round(bytes_fill / (avg["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
-            "whole_frame": {"achieved": round(bytes_frame / (frame_ms * 1e-3) / 1e9, 1),
-                            "frac": round(bytes_frame / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "device_ms": round(frame_ms, 5)},
+            "timing": "hipEvent pairs on the launch stream around each kernel group (kernels serialised for this "
+                      "measurement), mean of 30 frames; profiles/ holds the rocprofv3 per-kernel summary",
+            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); render_fast_kernel writes "
+                        f"the {hit_pixels} covered pixels, fill_kernel all {W * H}",
+            "note": "render_fast_kernel is VALU-issue/latency bound, not bandwidth bound (DESIGN.md section 5)",
+            "kernels_ms": {"hash_build+columns (3 kernels)": round(avg["bin"], 5),
+                           "fill_kernel": round(avg["fill"], 5),
+                           "render_fast_kernel+render_tiles_kernel": round(avg["render"], 5)},
+            "fill_kernel": {"achieved": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9, 1),
+                            "frac": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "whole_frame": {"achieved": round(bytes_frame / (ms_per_step * 1e-3) / 1e9, 1),
+                            "frac": round(bytes_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "ms_per_frame": round(ms_per_step, 5), "kernels_serial_ms": round(serial_ms, 5)},
             "occupied_columns": ncols, "columns": gx * gy,
         }
         # every ray traced, as the reference does (PAR_RENDER_TRACE_BACKGROUND)
         for i in range(3):
             r.render_device(ptrs, stream=stream, flags=par.RENDER_TRACE_BACKGROUND)
         torch.cuda.synchronize()
-        k = max(5, args.steps // 10)
+        k = max(5, min(200, args.steps // 10))
         t0 = time.perf_counter()
         for i in range(k):
             r.render_device(ptrs, stream=stream, flags=par.RENDER_TRACE_BACKGROUND)
