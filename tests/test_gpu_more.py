@@ -120,3 +120,54 @@ def test_other_bin_sizes_and_palettes(par, oracle, sprite, T):
             assert_planes_equal(r.render(ALL), exp, ALL, f"bin {bin_size} dense")
             fast = r.render(("fb", "palidx", "brightness", "gbuf"))
             assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"bin {bin_size}")
+
+
+def test_full_size_headline_frame(par, oracle, sprite, T):
+    """BASELINE's headline configuration itself: 4096x4096, 1024 primitives — bit-exact against the oracle (rows
+    split over the host cores), plus the properties that do not depend on the oracle: the default (background rays
+    skipped) and the every-ray-traced modes give the same frame, rendering is idempotent, and row blocks of any
+    alignment reproduce the rows of the whole frame."""
+    import os
+    w = h = l = 4096
+    params = T.default_params(w, h, l)
+    aabbs, light = par.scene_synthetic(1024, w, h, l, 12345)
+    exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb", "palidx"))
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        a = r.render(("fb", "palidx"))
+        assert a["fb"].tobytes() == exp["fb"].tobytes() and a["palidx"].tobytes() == exp["palidx"].tobytes()
+        b = r.render(("fb", "palidx"), flags=par.RENDER_TRACE_BACKGROUND)
+        assert b["fb"].tobytes() == a["fb"].tobytes() and b["palidx"].tobytes() == a["palidx"].tobytes()
+        c = r.render(("fb", "palidx"))
+        assert c["fb"].tobytes() == a["fb"].tobytes()
+        for r0, r1 in [(0, 512), (512, 1024), (3584, 4096), (1999, 2113)]:
+            blk = r.render(("fb",), rows=(r0, r1))
+            assert blk["fb"].tobytes() == a["fb"][r0 * w:r1 * w].tobytes(), (r0, r1)
+
+
+def test_host_demo_binary(par, oracle, T, tmp_path):
+    """The C++ host program (the reference's main loop on the C ABI) renders the default scene and its scripted
+    frames; its PPM output equals the oracle's frames with the debug line (SURVEY Appendix B frames)."""
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(par.LIB_PATH), "par_demo")
+    assert os.path.exists(demo), "build with make -C pixel-art-raytracer_amd/csrc"
+    p = subprocess.run([demo, "--keys", "RRRRUUUU", "--frames", "9", "--out", str(tmp_path), "--debug-line"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    params = T.default_params()
+    aabbs = par.scene_graybox(480, 320)
+    light = T.make_light(480, 160, 80)
+    sprite = par.tile_floor()
+    for f in range(9):
+        if f:
+            aabbs[0]["px" if f <= 4 else "pz"] += 5
+        out = oracle.render(params, aabbs, sprite, light, planes=("fb", "gbuf"))
+        fb = out["fb"]
+        oracle.debug_line(params, out["gbuf"], light, 0, 0, fb)
+        raw = open(tmp_path / f"frame_{f:03d}.ppm", "rb").read()
+        header = b"P6\n480 320\n255\n"
+        assert raw.startswith(header)
+        rgb = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(-1, 3)
+        assert np.array_equal(rgb[:, 0], fb["red"]) and np.array_equal(rgb[:, 1], fb["green"]) and \
+            np.array_equal(rgb[:, 2], fb["blue"]), f"frame {f}"
