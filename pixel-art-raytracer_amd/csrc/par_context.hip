@@ -251,16 +251,16 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // the render kernels overwrite the tiles primitives reach. (Timed runs keep everything on one stream so that
     // the event pairs bracket single kernels.)
     const bool fork = !ev && !r.dense;
-    if (fork) {
+    if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
+    PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
+    // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
+    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
+    if (fork) {  // (after the two tiny build kernels: beside them the fill only slows them down)
         PAR_HIP(hipEventRecord(ctx->ev_fork, stream));
         PAR_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
         PAR_HIP(par_launch_fill(ctx->grid, r, ctx->stream2));
         PAR_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
     }
-    if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
-    PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
-    // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
-    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
     // occupied columns <= (entity, bin) pairs
     const int64_t col_bound = graph_mode ? ctx->grid.capacity : ctx->total_pairs;
     PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));

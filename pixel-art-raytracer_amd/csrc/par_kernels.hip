@@ -274,7 +274,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// columns_kernel: one workgroup (2 wavefronts) per occupied screen column (bx, by).
+// columns_kernel: one workgroup (4 wavefronts) per occupied screen column (bx, by).
 //   A. the column's bins, front to back: compact list of the occupied ones and their slot records;
 //   B. one wavefront per occupied bin walks from it to the light as trace_hash_for_light does (alt:399-500). The
 //      probed bin sequence depends only on the start and light bins, not on the ray, so it is done ONCE per bin
@@ -290,15 +290,15 @@ struct ColShared {
     par_colrec_nb nb[PAR_COL_NB];
     par_slot entries[PAR_COL_ENT];
     int16_t ebz[PAR_COL_ENT];
-    par_slot stage[2][PAR_BIN_WALK];  // per wavefront: the records of the walk it is doing
-    int16_t chain[2][3][65];
-    int32_t wsum[2];
+    par_slot stage[4][PAR_BIN_WALK];  // per wavefront: the records of the walk it is doing
+    int16_t chain[4][3][65];
+    int32_t wsum[4];
     int32_t n_walk;
     int32_t overflow;
     int32_t tile_mode;
 };
 
-__global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render_args a) {
+__global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render_args a) {
     __shared__ ColShared sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = (int)blockIdx.x;
@@ -318,12 +318,12 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
     // ---- A: ordered compaction of the column ------------------------------------------------------------------
     int nb_base = 0, ent_base = 0;
     bool over = false;
-    for (int t0 = 0; t0 < g.gz; t0 += 128) {
+    for (int t0 = 0; t0 < g.gz; t0 += 256) {
         const int t = t0 + tid;
         const par_slot* src = a.slots + (size_t)(col_base + min(t, g.gz - 1)) * PAR_SLOTS;
         const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;
         int total;
-        const int packed = block_excl_scan<2>(((c != 0) << 16) | c, sm.wsum, total);
+        const int packed = block_excl_scan<4>(((c != 0) << 16) | c, sm.wsum, total);
         const int nb_i = nb_base + (packed >> 16);
         const int off = ent_base + (packed & 0xFFFF);
         if (c != 0) {
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(128) void columns_kernel(par_grid_dev g, par_render
         const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
         int16_t(*chain)[65] = sm.chain[wave];
         par_slot* stage = sm.stage[wave];
-        for (int i = wave; i < n_nb; i += 2) {  // wave-uniform
+        for (int i = wave; i < n_nb; i += 4) {  // wave-uniform
             const int sx = bx, sy = by, sz = sm.nb[i].bz;
             const int b0 = col_base + sz;
             // alt:406-430
@@ -1233,7 +1233,7 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     const int64_t blocks = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(128), 0, stream, g, a);
+    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
     return hipGetLastError();
 }
 
@@ -1278,9 +1278,10 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     }
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound <= 0) return hipSuccess;
-    // 5 resident workgroups per CU (7 wavefronts per SIMD): more would only queue behind them, and a workgroup
-    // that takes several columns overlaps the next record's load with the current column's pixels
-    const int64_t cap = (int64_t)256 * 5;
+    // 4 workgroups per CU: all of them are resident from the first microsecond (5 would fit by the register and
+    // LDS budgets, but the dispatcher does not spread them perfectly and the stragglers start a whole workgroup
+    // late); a workgroup that takes several columns overlaps the next record's load with the current column's pixels
+    const int64_t cap = (int64_t)256 * 4;
     // (a column is split into up to 8 work items when there are fewer columns than resident workgroups)
     hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)(bound * 8 > cap ? cap : bound * 8)), dim3(PAR_NT), 0, stream, g, a);
     hipError_t e = hipGetLastError();
