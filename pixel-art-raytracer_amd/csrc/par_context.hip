@@ -135,7 +135,7 @@ int reset_grid(par_context* ctx) {
         PAR_HIP(hipMemsetAsync(ctx->grid.count[s], 0, (size_t)ctx->volume, ctx->stream));
         PAR_HIP(hipMemsetAsync(ctx->grid.colflag[s], 0, (size_t)ctx->gx * ctx->gy * sizeof(int32_t), ctx->stream));
     }
-    PAR_HIP(hipMemsetAsync(ctx->grid.counters, 0, 4 * sizeof(int32_t), ctx->stream));
+    PAR_HIP(hipMemsetAsync(ctx->grid.counters, 0, PAR_CNT_TOTAL * sizeof(int32_t), ctx->stream));
     PAR_HIP(hipMemsetAsync(ctx->grid.node_counter, 0, 2 * sizeof(int32_t), ctx->stream));
     PAR_HIP(hipStreamSynchronize(ctx->stream));
     ctx->set = 0;
@@ -369,7 +369,7 @@ int par_create(const par_params* params, int device, par_context** out) {
         if ((e = hipMalloc(&ctx->grid.colflag[s], (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     }
     if ((e = hipMalloc(&ctx->grid.col_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
-    if ((e = hipMalloc(&ctx->grid.counters, 4 * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.counters, PAR_CNT_TOTAL * sizeof(int32_t))) != hipSuccess) return bail(e);
     if (const char* dbg = std::getenv("PAR_DEBUG_STAMPS"); dbg && dbg[0] == '1') {
         const size_t bytes = (size_t)2 * PAR_STAMP_WGS * PAR_STAMP_SLOTS * sizeof(unsigned long long);
         if ((e = hipMalloc(&ctx->grid.stamps, bytes)) != hipSuccess) return bail(e);

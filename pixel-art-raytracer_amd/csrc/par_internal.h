@@ -80,7 +80,7 @@ struct par_grid_dev {
     int32_t* node_bin[2];     // [capacity]
     int32_t* node_counter;    // [2]
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
-    int32_t* counters;        // [4]: occupied columns, overflowed columns, spare (reset by insert)
+    int32_t* counters;        // [PAR_CNT_TOTAL]: occupied columns, overflowed columns, work distribution (reset by insert)
     par_colrec* colrec;       // [col_capacity] indexed like col_list
     int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
     unsigned long long* stamps;  // debug (PAR_DEBUG_STAMPS=1): per workgroup phase time stamps, else nullptr
@@ -123,7 +123,8 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
-enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1 };
+constexpr int PAR_SCHED_GROUPS = 64;  // work-distribution counters of render_fast_kernel
+enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_SCHED = 8, PAR_CNT_TOTAL = PAR_CNT_SCHED + PAR_SCHED_GROUPS };
 
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin
         g.count[o][b] = 0;
         g.colflag[o][b / g.gz] = 0;
     }
-    if (tid < 2) g.counters[tid] = 0;
+    if (tid < PAR_CNT_TOTAL) g.counters[tid] = 0;
 
     const int W = a.W, H = a.H, L = a.L, B = a.B;
     const int lane = threadIdx.x & 63;
@@ -606,25 +606,35 @@ struct FastShared {
     par_texel texinfo[PAR_SPRITE_TEXELS];      // sprite 0: normal + resolved palette colour per texel
     int32_t sprite_depth[PAR_SPRITE_TEXELS];   // sprite 0: depth per texel (the hot lookup of the primary pass)
     uint8_t sprite_color[PAR_SPRITE_TEXELS];   // sprite 0: palette index per texel
+    int32_t next[2];                           // work items handed out by the group counter
 };
 
-__global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par_render_args a) {
+__global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, par_render_args a) {
     __shared__ FastShared sm;
     const int tid = threadIdx.x;
     const int W = a.W, H = a.H, B = a.B;
     stamp(g, 1, 0);
     const int n_cols = min(g.counters[PAR_CNT_COLS], g.col_capacity);
-    if (n_cols <= 0 || (int)blockIdx.x >= n_cols * max(1, min(8, (int)gridDim.x / n_cols))) return;
+    if (n_cols <= 0) return;
     constexpr int NV = (int)(sizeof(par_colrec) / 16);  // 16-byte pieces of a record: one per lane
     static_assert(NV <= PAR_NT, "one record piece per lane");
-    // A column is split into `parts` work items when there are fewer columns than resident workgroups (small
-    // frames), so that the whole chip still has something to do.
-    const int stride = (int)gridDim.x;
-    const int parts = max(1, min(8, stride / n_cols));
+    // A column is split into `parts` work items when there are fewer columns than workgroups (small frames), so
+    // that the whole chip still has something to do.
+    const int parts = max(1, min(8, (int)gridDim.x / n_cols));
     const int n_items = n_cols * parts;
-    int w = (int)blockIdx.x;
+    // Work distribution. Column costs differ several-fold, so a fixed assignment leaves the slowest workgroup far
+    // behind; but atomics on ONE address are served one after the other (~8 ns each on this chip), so a single
+    // shared counter would cost every workgroup tens of microseconds at start-up. Hence: the items are dealt to
+    // PAR_SCHED_GROUPS groups (item i belongs to group i % groups), each workgroup's first two items are fixed (no
+    // atomic), and only later ones come off the group's own counter -- a handful of atomics per counter and frame.
+    // The atomic of item k+2 is issued at the start of item k and consumed at its end.
+    const int sched_q = (int)blockIdx.x % PAR_SCHED_GROUPS, sched_j = (int)blockIdx.x / PAR_SCHED_GROUPS;
+    const int sched_wpg = ((int)gridDim.x + PAR_SCHED_GROUPS - 1) / PAR_SCHED_GROUPS;  // workgroups per group
+    int item = sched_q + PAR_SCHED_GROUPS * sched_j;
+    int item_next = sched_q + PAR_SCHED_GROUPS * (sched_j + sched_wpg);
+    if (item >= n_items) return;
     uint4 piece = make_uint4(0, 0, 0, 0);
-    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + w / parts)[tid];
+    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + item / parts)[tid];
 
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
@@ -635,15 +645,19 @@ __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par
         sm.sprite_color[t] = (uint8_t)a.sprites[0].color[t];
     }
     stamp(g, 1, 1);
-    for (int buf = 0;; buf ^= 1, w += stride) {
+    for (int it = 0;; it++) {
+        const int buf = it & 1;
         if (tid < NV) reinterpret_cast<uint4*>(&sm.rec[buf])[tid] = piece;
+        int fetched = 0;
+        if (tid == 0) fetched = atomicAdd(&g.counters[PAR_CNT_SCHED + sched_q], 1);  // -> item it + 2
         // One barrier per work item: the buffer written now was last read two items ago, and every lane has passed
         // the previous item's barrier since.
         __syncthreads();
-        if (w == (int)blockIdx.x) stamp(g, 1, 2);
-        const bool has_next = w + stride < n_items;
-        if (has_next && tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + (w + stride) / parts)[tid];
-        const int part = w - (w / parts) * parts;
+        if (it == 0) stamp(g, 1, 2);
+        if (it > 0) item_next = sm.next[(it - 1) & 1];  // fetched during the previous item
+        const bool has_next = item_next < n_items;
+        if (has_next && tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + item_next / parts)[tid];
+        const int part = item - (item / parts) * parts;
         const par_colrec& rec_ = sm.rec[buf];
         const int n_entries = (rec_.overflow || (a.flags & (1u << 24))) ? 0 : rec_.n_entries;  // bit 24: ablation
         const int n_nb = rec_.n_nb;
@@ -830,8 +844,10 @@ __global__ __launch_bounds__(PAR_NT) void render_fast_kernel(par_grid_dev g, par
             }
             }  // passes over the rectangle
         }      // entries
-        if (w == (int)blockIdx.x) stamp(g, 1, 3);
+        if (it == 0) stamp(g, 1, 3);
+        if (tid == 0) sm.next[buf] = sched_q + PAR_SCHED_GROUPS * (2 * sched_wpg + fetched);
         if (!has_next) break;
+        item = item_next;
     }
     stamp(g, 1, 4);
 }
@@ -1278,10 +1294,10 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     }
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound <= 0) return hipSuccess;
-    // 4 workgroups per CU: all of them are resident from the first microsecond (5 would fit by the register and
-    // LDS budgets, but the dispatcher does not spread them perfectly and the stragglers start a whole workgroup
-    // late); a workgroup that takes several columns overlaps the next record's load with the current column's pixels
-    const int64_t cap = (int64_t)256 * 4;
+    // Persistent workgroups, 5 per CU (what is resident at once with 64 VGPRs and 24 KB of LDS per workgroup of 5
+    // wavefronts: measured, a sixth per CU starts only when another has finished). They take their work items off
+    // per-group counters, and the next record's load overlaps the current column's pixels.
+    const int64_t cap = (int64_t)256 * 5;
     // (a column is split into up to 8 work items when there are fewer columns than resident workgroups)
     hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)(bound * 8 > cap ? cap : bound * 8)), dim3(PAR_NT), 0, stream, g, a);
     hipError_t e = hipGetLastError();

@@ -32,7 +32,12 @@ for k, name, labels in ((0, "columns_kernel", ["start", "listed", "A done", "B w
     x = x[live]
     t0 = x[:, 0].min()
     print(f"{name}: {live.sum()} workgroups finished; kernel span {x[:,4].max()-t0:.1f} us")
-    print(f"   start times: min 0, median {np.median(x[:,0])-t0:.1f}, max {x[:,0].max()-t0:.1f} us")
+    print(f"   start times: min 0, median {np.median(x[:,0])-t0:.1f}, max {x[:,0].max()-t0:.1f} us; "
+          f"p75 {np.percentile(x[:,0],75)-t0:.1f} p90 {np.percentile(x[:,0],90)-t0:.1f} p99 {np.percentile(x[:,0],99)-t0:.1f}; "
+          f"late (>2us): {(x[:,0]-t0>2).sum()}")
+    late = np.nonzero(x[:, 0] - t0 > 2)[0]
+    ids = np.nonzero(live)[0][late]
+    print("   late workgroup ids (first 24):", ids[:24].tolist(), " id%8:", sorted(set((ids % 8).tolist())))
     for i in range(1, 5):
         d = x[:, i] - x[:, i - 1]
         print(f"   {labels[i-1]:>16s} -> {labels[i]:<16s}: median {np.median(d):6.2f}  p90 {np.percentile(d,90):6.2f}  max {d.max():6.2f} us")
