@@ -11,6 +11,10 @@ palette-index plane. Scene, sprites and output buffers are resident in HBM befor
 same frame is sharded by row block (rank r renders rows [H r/N, H (r+1)/N)) and the blocks are gathered to rank 0
 with one RCCL gather per frame (strong scaling: total work is fixed as N grows).
 
+Frames in flight: like a swap chain, `--inflight` (default 3) frames are in flight at once, each with its own context,
+stream and output buffers (pixel-art-raytracer_amd/pipeline.py); one frame alone is a chain of short latency-bound
+kernels that leaves most of the chip idle. `--inflight 1` gives the one-frame-at-a-time rate.
+
 Mrays/s is nominal = 2 * W * H * frames / seconds (the reference casts exactly one primary and one shadow ray per
 pixel, background included: alt:277-279, 703, 738). The GPU path skips the shadow ray of background pixels, whose
 colour cannot depend on it (SURVEY a-6); the count actually traced and the rate with every ray traced are reported
@@ -68,6 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight (contexts/streams/buffers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,38 +99,38 @@ def main():
     params = T.default_params(W, H, L)
     aabbs, light = par.scene_synthetic(N_PRIMS, W, H, L, SEED)
     sprite = par.tile_floor()
-    r = par.Renderer(params, local_rank)
-    r.set_scene(aabbs, sprite, light)
+    pipeline = importlib.import_module("pixel-art-raytracer_amd.pipeline")
 
     r0, r1 = sharding.row_block(rank, world, H)
     gather = None
+    rows_alloc = H
     if world > 1:
         gather = sharding.FrameGather(H, W * 4, torch.uint8, dev, world, rank)
-        nbuf = 2
         rows_alloc = gather.max_rows
-    else:
-        nbuf = 1
-        rows_alloc = H
-    fb = [torch.zeros(rows_alloc * W * 4, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    pal = [torch.zeros(rows_alloc * W, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    stream = torch.cuda.current_stream().cuda_stream
-    pending = [None] * nbuf
+    depth = max(1, args.inflight)
+    pipe = pipeline.FramePipeline(params, aabbs, sprite, light, depth=depth, device=local_rank, rows=(r0, r1),
+                                  planes=("fb", "palidx"), rows_alloc=rows_alloc)
+    r = pipe.slots[0].renderer
+    fb = [s_.buffers["fb"] for s_ in pipe.slots]
+    pal = [s_.buffers["palidx"] for s_ in pipe.slots]
 
     def step(i, flags=0):
-        b = i % nbuf
-        if pending[b] is not None:  # the gather that last read this block buffer
-            pending[b].wait()
-            pending[b] = None
-        r.render_device({"fb": fb[b].data_ptr(), "palidx": pal[b].data_ptr()}, rows=(r0, r1), flags=flags,
-                        stream=stream)
-        if gather is not None:
-            pending[b] = gather.gather(fb[b], async_op=True)
+        slot = pipe.slot(i)
+        with torch.cuda.stream(slot.stream):
+            if slot.pending is not None:  # the gather that last read this slot's block buffer
+                slot.pending.wait()
+                slot.pending = None
+            pipe.submit(i, flags)
+            if gather is not None:
+                slot.pending = gather.gather(slot.buffers["fb"], async_op=True)
 
     def drain():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        for slot in pipe.slots:
+            with torch.cuda.stream(slot.stream):
+                if slot.pending is not None:
+                    slot.pending.wait()
+                    slot.pending = None
+        pipe.synchronize()
         if gather is not None:
             gather.unpack()
         torch.cuda.synchronize()
@@ -137,7 +142,7 @@ def main():
 
     # correctness of what is about to be timed (before the warm-up, so that the GPU does not idle between warm-up
     # and the timed region): rank 0 renders the whole frame alone and compares
-    for i in range(2):
+    for i in range(depth):
         step(i)
     drain()
     verified = None
@@ -146,8 +151,8 @@ def main():
         if world > 1:
             verified = bool(np.array_equal(gather.frame.cpu().numpy(), full["fb"].view(np.uint8)))
         else:
-            verified = bool(np.array_equal(fb[0].cpu().numpy(), full["fb"].view(np.uint8)) and
-                            np.array_equal(pal[0].cpu().numpy(), full["palidx"]))
+            verified = all(bool(np.array_equal(fb[k].cpu().numpy(), full["fb"].view(np.uint8)) and
+                                np.array_equal(pal[k].cpu().numpy(), full["palidx"])) for k in range(depth))
         hit_pixels = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
     barrier()
 
@@ -181,7 +186,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "4096x4096x4096 view, bin 40, 1024 primitives (splitmix64 seed 12345), "
                                    "light (2560,2048,1024); RGBA8 frame + palette-index plane",
-                       "sharding": f"row blocks over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else "")},
+                       "sharding": f"row blocks over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "frames_in_flight": depth},
             "frames_per_s": round(args.steps / elapsed, 1),
             "mpix_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
             "rays": {"nominal_per_frame": int(rays_per_frame), "traced_per_frame": int(W * H + hit_pixels),
@@ -192,6 +198,16 @@ def main():
     # ---- roofline of the dominant kernel + the all-rays-traced rate (N = 1 only; untimed extras) -------------
     if world == 1:
         ptrs = {"fb": fb[0].data_ptr(), "palidx": pal[0].data_ptr()}
+        stream = torch.cuda.current_stream().cuda_stream
+        # one frame at a time (no other frame in flight): the latency of a frame and its kernels
+        for i in range(20):
+            r.render_device(ptrs, stream=stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(200):
+            r.render_device(ptrs, stream=stream)
+        torch.cuda.synchronize()
+        out["one_frame_at_a_time"] = {"ms_per_frame": round((time.perf_counter() - t0) / 200 * 1e3, 5)}
         ms = {"bin": [], "fill": [], "render": []}
         for _ in range(5):
             r.render_device(ptrs, stream=stream, timed=True)
@@ -253,7 +269,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(out))
-    r.close()
+    pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -18,14 +18,11 @@ struct par_context {
     int device = 0;
     int gx = 0, gy = 0, gz = 0, volume = 0;
     hipStream_t stream = nullptr;   // used by the synchronous host-buffer entry points
-    hipStream_t stream2 = nullptr;  // the background fill runs here, beside the hash build
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // host mirrors
     std::vector<par_aabb> h_aabbs;
     std::vector<int32_t> h_pairs;  // (entity, bin) pairs each entity inserts, alt:243-267
-    std::vector<int32_t> h_tiles;  // render tiles each entity's screen rectangle can touch
-    int64_t total_pairs = 0, total_tiles = 0;
+    int64_t total_pairs = 0;
     int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
     bool have_light = false, have_entities = false;
     par_light light{};
@@ -52,6 +49,7 @@ struct par_context {
     par_frame_dyn* pin_dyn = nullptr;
     par_frame_dyn* d_dyn = nullptr;
     int graph_set = 0;
+    int64_t graph_pair_bound = 0;  // (entity, bin) pairs a captured graph's launch grids can take
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     par_frame_stats stats{};
@@ -93,20 +91,6 @@ int64_t pairs_of(const par_context* c, const par_aabb& a) {
     const int z1 = std::min(c->gz, (maxz + B - 1) / B);
     if (x1 <= x0 || y1 <= y0 || z1 <= z0) return 0;
     return (int64_t)(x1 - x0) * (y1 - y0) * (z1 - z0);
-}
-
-// Render tiles (bin-wide, PAR_NT / bin rows tall) the screen rectangle of one AABB can touch: an upper bound of the
-// tiles it puts on the work lists. Columns come from its x bins, rows from alt:314-317 (H - world_j).
-int64_t tiles_of(const par_context* c, const par_aabb& a) {
-    const int W = c->params.width, H = c->params.height, B = c->params.bin_size;
-    const int minx = a.px, maxx = a.px + a.ex;
-    if (maxx < 0 || minx >= W) return 0;
-    const int x0 = std::max(0, minx / B), x1 = std::min(c->gx, (maxx + B - 1) / B);
-    const int lo = std::max(0, H - (a.py + a.ey) - (a.pz + a.ez)), hi = std::min(H, H - a.py - a.pz);
-    if (x1 <= x0 || hi <= lo) return 0;
-    const int tr = PAR_NT / B, subs = c->grid.subs;
-    auto tile_row = [&](int j) { return (j / B) * subs + (j % B) / tr; };
-    return (int64_t)(x1 - x0) * (tile_row(hi - 1) - tile_row(lo) + 1);
 }
 
 bool extent_ok(const par_aabb& a) {
@@ -247,30 +231,21 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
     }
-    // The background fill does not depend on the hash: it runs on a second stream beside the build and joins before
-    // the render kernels overwrite the tiles primitives reach. (Timed runs keep everything on one stream so that
-    // the event pairs bracket single kernels.)
-    const bool fork = !ev && !r.dense;
+    // The background fill does not depend on the hash; it goes first on the same stream. (Forking it onto a second
+    // stream beside the build was measured slower, alone and with several frames in flight: the cross-stream
+    // event costs more than the overlap gains, and frames in flight fill the idle CUs anyway.)
+    if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
+    PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
     PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
-    // In graph mode the pair count of future frames is unknown at capture time: bound it by the pool capacity.
-    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, graph_mode ? ctx->grid.capacity : ctx->total_pairs, stream));
-    if (fork) {  // (after the two tiny build kernels: beside them the fill only slows them down)
-        PAR_HIP(hipEventRecord(ctx->ev_fork, stream));
-        PAR_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-        PAR_HIP(par_launch_fill(ctx->grid, r, ctx->stream2));
-        PAR_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
-    }
+    // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
+    // what par_graph_stage accepts (graph_pair_bound); beyond it the caller captures again.
+    const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : ctx->total_pairs;
+    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, stream));
     // occupied columns <= (entity, bin) pairs
-    const int64_t col_bound = graph_mode ? ctx->grid.capacity : ctx->total_pairs;
+    const int64_t col_bound = pair_bound;
     PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
-    if (fork) {
-        PAR_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
-    } else {
-        PAR_HIP(par_launch_fill(ctx->grid, r, stream));
-    }
-    if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
@@ -384,9 +359,6 @@ int par_create(const par_params* params, int device, par_context** out) {
         return PAR_ERR_UNSUPPORTED;
     }
     if ((e = hipMalloc(&ctx->grid.slow_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
-    if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) return bail(e);
-    if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail(e);
-    if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.slots, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.node_counter, 2 * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->d_palette, PAR_MAX_PALETTE * sizeof(par_color))) != hipSuccess) return bail(e);
@@ -420,9 +392,6 @@ void par_destroy(par_context* ctx) {
         if (ctx->grid.count[s]) (void)hipFree(ctx->grid.count[s]);
         if (ctx->grid.colflag[s]) (void)hipFree(ctx->grid.colflag[s]);
     }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.slow_list, ctx->grid.stamps};
     for (void* p : lists) {
         if (p) (void)hipFree(p);
@@ -494,15 +463,13 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
     drop_graphs(ctx);
-    std::vector<int32_t> pairs((size_t)n), tiles((size_t)n);
-    int64_t total = 0, total_t = 0;
+    std::vector<int32_t> pairs((size_t)n);
+    int64_t total = 0;
     for (int i = 0; i < n; i++) {
         const int64_t k = pairs_of(ctx, aabbs[i]);
         if (k > 0x7FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "entity spans too many bins");
         pairs[(size_t)i] = (int32_t)k;
         total += k;
-        tiles[(size_t)i] = (int32_t)tiles_of(ctx, aabbs[i]);
-        total_t += tiles[(size_t)i];
     }
     int rc = ensure_pool(ctx, total);
     if (rc != PAR_OK) return rc;
@@ -522,9 +489,7 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     }
     ctx->h_aabbs.assign(aabbs, aabbs + n);
     ctx->h_pairs.swap(pairs);
-    ctx->h_tiles.swap(tiles);
     ctx->total_pairs = total;
-    ctx->total_tiles = total_t;
     ctx->n_entities = n;
     ctx->max_sprite_id = max_id;
     ctx->have_entities = true;
@@ -565,13 +530,10 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    std::vector<int32_t> np((size_t)n), nt((size_t)n);
-    int64_t total_t = ctx->total_tiles;
+    std::vector<int32_t> np((size_t)n);
     for (int i = 0; i < n; i++) {
         np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i]);
         total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
-        nt[(size_t)i] = (int32_t)tiles_of(ctx, aabbs[i]);
-        total_t += nt[(size_t)i] - ctx->h_tiles[(size_t)(first + i)];
     }
     PAR_HIP(hipSetDevice(ctx->device));
     int rc = ensure_pool(ctx, total);
@@ -582,10 +544,8 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     for (int i = 0; i < n; i++) {
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
-        ctx->h_tiles[(size_t)(first + i)] = nt[(size_t)i];
     }
     ctx->total_pairs = total;
-    ctx->total_tiles = total_t;
     return PAR_OK;
 }
 
@@ -631,9 +591,9 @@ int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int r
     ctx->set ^= 1;
     ctx->last_flags = flags;
     PAR_HIP(hipEventSynchronize(ctx->ev[2]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_fill, ctx->ev[3], ctx->ev[0]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_bin, ctx->ev[0], ctx->ev[1]));
-    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_fill, ctx->ev[1], ctx->ev[3]));
-    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[3], ctx->ev[2]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[1], ctx->ev[2]));
     if (stats) return par_get_stats(ctx, stats);
     return PAR_OK;
 }
@@ -651,7 +611,8 @@ int par_graph_capture(par_context* ctx, void* stream_v, int row_begin, int row_e
     PAR_HIP(hipDeviceSynchronize());
     drop_graphs(ctx);
     // Head-room for moving primitives: pair counts of later frames are only bounded by the pool.
-    rc = ensure_pool(ctx, ctx->total_pairs * 2 + 4096);
+    ctx->graph_pair_bound = ctx->total_pairs * 2 + 4096;
+    rc = ensure_pool(ctx, ctx->graph_pair_bound);
     if (rc != PAR_OK) return rc;
     if (!ctx->pin_aabbs) {
         PAR_HIP(hipHostMalloc(&ctx->pin_aabbs, (size_t)std::max(ctx->aabb_capacity, 1) * sizeof(par_aabb), hipHostMallocDefault));
@@ -688,7 +649,9 @@ int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, c
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
         total += pairs_of(ctx, aabbs[i]) - ctx->h_pairs[(size_t)(first + i)];
     }
-    if (total > ctx->grid.capacity) return fail(ctx, PAR_ERR_UNSUPPORTED, "staged frame exceeds the captured node pool; capture again");
+    if (total > ctx->graph_pair_bound || total > ctx->grid.capacity) {
+        return fail(ctx, PAR_ERR_UNSUPPORTED, "staged frame exceeds what the captured graph was sized for; capture again");
+    }
     for (int i = 0; i < n; i++) {
         ctx->h_pairs[(size_t)(first + i)] = (int32_t)pairs_of(ctx, aabbs[i]);
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
