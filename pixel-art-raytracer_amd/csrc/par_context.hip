@@ -35,6 +35,8 @@ struct par_context {
     par_color* d_palette = nullptr;
     par_texel* d_texinfo = nullptr;
     unsigned long long* d_ray_counter = nullptr;
+    uint8_t* d_scratch_lit = nullptr;  // lit plane when every ray is traced but the caller wants no lit plane
+    size_t scratch_lit_bytes = 0;
     par_grid_dev grid{};
     int aabb_capacity = 0;
 
@@ -192,8 +194,11 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.subs = c->grid.subs;
     a.set = set;
     a.magic_tr = (uint32_t)((1ull << 32) / (uint64_t)a.tile_rows + 1ull);
-    // every ray traced (as the reference does), or the lit plane requested: every column goes through the tracer
-    a.dense = ((flags & PAR_RENDER_TRACE_BACKGROUND) || out.lit) ? 1 : 0;
+    // every ray traced (as the reference does), or the lit plane requested
+    a.trace_bg = ((flags & PAR_RENDER_TRACE_BACKGROUND) || out.lit) ? 1 : 0;
+    // PAR_FORCE_GENERIC=1 (testing): every tile goes through the self-contained generic kernel
+    static const bool force_generic = [] { const char* e = std::getenv("PAR_FORCE_GENERIC"); return e && e[0] == '1'; }();
+    a.dense = force_generic ? 1 : 0;
     a.magic_b = (uint32_t)((1ull << 32) / (uint64_t)B + 1ull);
     a.ambient = c->params.ambient;
     a.background = c->params.background;
@@ -226,16 +231,26 @@ par_bin_args make_bin_args(const par_context* c, int set, int row_begin, int row
 // Enqueue one frame (alt:690-760) on `stream` using grid set `set`.
 int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, int row_end, const par_outputs& out,
                   unsigned flags, bool graph_mode, hipEvent_t* ev) {
+    par_outputs outs = out;
+    if ((flags & PAR_RENDER_TRACE_BACKGROUND) && !outs.lit) {
+        // every ray is to be traced but the caller wants no lit plane: the results still go to memory (a scratch
+        // plane of the context), so the work is real and can be inspected
+        const size_t need = (size_t)(row_end - row_begin) * ctx->params.width;
+        if (ctx->scratch_lit_bytes < need) {
+            if (graph_mode) return fail(ctx, PAR_ERR_NOT_READY, "render once with PAR_RENDER_TRACE_BACKGROUND before capturing it");
+            if (ctx->d_scratch_lit) PAR_HIP(hipFree(ctx->d_scratch_lit));
+            ctx->d_scratch_lit = nullptr;
+            ctx->scratch_lit_bytes = 0;
+            PAR_HIP(hipMalloc(&ctx->d_scratch_lit, need));
+            ctx->scratch_lit_bytes = need;
+        }
+        outs.lit = ctx->d_scratch_lit;
+    }
     const par_bin_args b = make_bin_args(ctx, set, row_begin, row_end);
-    const par_render_args r = make_render_args(ctx, set, row_begin, row_end, out, flags, graph_mode);
+    const par_render_args r = make_render_args(ctx, set, row_begin, row_end, outs, flags, graph_mode);
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
     }
-    // The background fill does not depend on the hash; it goes first on the same stream. (Forking it onto a second
-    // stream beside the build was measured slower, alone and with several frames in flight: the cross-stream
-    // event costs more than the overlap gains, and frames in flight fill the idle CUs anyway.)
-    if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
-    PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
     PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
@@ -246,6 +261,12 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     const int64_t col_bound = pair_bound;
     PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
+    // The background fill goes on the same stream. (Forking it onto a second stream beside the build was measured
+    // slower, alone and with several frames in flight: the cross-stream events cost more than the overlap gains,
+    // and frames in flight fill the idle CUs anyway.) It follows the column kernels because, when background rays
+    // are traced, it copies their results into the lit plane.
+    PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
@@ -359,6 +380,9 @@ int par_create(const par_params* params, int device, par_context** out) {
         return PAR_ERR_UNSUPPORTED;
     }
     if ((e = hipMalloc(&ctx->grid.slow_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.bgwalk, (size_t)gx * sizeof(par_bgwalk))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.bglit, (size_t)p.width + 64)) != hipSuccess) return bail(e);
+    if ((e = hipMemset(ctx->grid.bglit, 1, (size_t)p.width + 64)) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.slots, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.node_counter, 2 * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->d_palette, PAR_MAX_PALETTE * sizeof(par_color))) != hipSuccess) return bail(e);
@@ -392,7 +416,8 @@ void par_destroy(par_context* ctx) {
         if (ctx->grid.count[s]) (void)hipFree(ctx->grid.count[s]);
         if (ctx->grid.colflag[s]) (void)hipFree(ctx->grid.colflag[s]);
     }
-    void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.slow_list, ctx->grid.stamps};
+    void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.slow_list, ctx->grid.stamps, ctx->grid.bgwalk,
+                     ctx->grid.bglit, ctx->d_scratch_lit};
     for (void* p : lists) {
         if (p) (void)hipFree(p);
     }
@@ -591,9 +616,9 @@ int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int r
     ctx->set ^= 1;
     ctx->last_flags = flags;
     PAR_HIP(hipEventSynchronize(ctx->ev[2]));
-    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_fill, ctx->ev[3], ctx->ev[0]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_bin, ctx->ev[0], ctx->ev[1]));
-    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[1], ctx->ev[2]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_fill, ctx->ev[1], ctx->ev[3]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[3], ctx->ev[2]));
     if (stats) return par_get_stats(ctx, stats);
     return PAR_OK;
 }

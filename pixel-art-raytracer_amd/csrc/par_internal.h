@@ -62,6 +62,15 @@ struct par_colrec {
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 constexpr int PAR_MAX_SUBS = 96;  // tiles per column the cover mask can describe
 
+// The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world
+// position (x, 0, 0) (alt:281, 707-709), so its ray starts in bin (x / B, H / B, 0) whatever its row -- one walk per
+// bin column bx, one ray per x.
+struct par_bgwalk {
+    int32_t cnt;  // records, or -1 when they did not fit
+    int32_t pad_[3];
+    par_slot rec[PAR_BIN_WALK];
+};
+
 // Per-frame values that change without the scene being re-uploaded. In the hipGraph path they live in device memory
 // (updated by a memcpy node); otherwise they travel as kernel arguments.
 struct par_frame_dyn {
@@ -83,6 +92,8 @@ struct par_grid_dev {
     int32_t* counters;        // [PAR_CNT_TOTAL]: occupied columns, overflowed columns, work distribution (reset by insert)
     par_colrec* colrec;       // [col_capacity] indexed like col_list
     int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
+    par_bgwalk* bgwalk;       // [gx] shadow walks of the background rays (traced only on request)
+    uint8_t* bglit;           // [width] result of the background ray of screen column x
     unsigned long long* stamps;  // debug (PAR_DEBUG_STAMPS=1): per workgroup phase time stamps, else nullptr
     int32_t capacity;
     int32_t col_capacity;
@@ -104,6 +115,7 @@ struct par_render_args {
     int32_t tile_rows;             // rows per workgroup tile: PAR_NT / B
     int32_t subs;                  // tiles per bin row = ceil(B / tile_rows)
     int32_t set;                   // grid set of this frame
+    int32_t trace_bg;              // 1: background shadow rays are traced too (flag, or lit plane requested)
     int32_t dense;                 // 1: every column is rendered by render_tiles (every ray traced), no fill pass
     uint32_t magic_b;              // floor(n / B) == __umulhi(n, magic_b) for n * B < 2^32
     float ambient;
@@ -130,6 +142,9 @@ enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_SCHED = 8, PAR_CNT_TOTAL = PA
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
 // Per occupied column: compact slot list, the shadow walks of its bins, and its tiles onto the work lists.
+hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
+// Per occupied column: compact slot list + the shadow walks of its bins (+ the background walks when a.trace_bg);
+// then, when a.trace_bg, the background rays themselves (one per x).
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
 // Background for every pixel of the row range (skipped when a.dense); the render kernels then overwrite the tiles
 // primitives reach. Independent of the hash: may run beside the build on another stream.

@@ -274,6 +274,91 @@ __device__ __forceinline__ int xcd_remap(int b, int nb) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// wave_walk: ONE wavefront walks from bin (sx, sy, sz) to the light's bin as trace_hash_for_light does
+// (alt:399-500) and stages the slot records of every occupied bin on the way (start bin excluded, alt:471-473) in
+// `stage` (LDS, PAR_BIN_WALK records). Returns their number, or -1 when they do not fit. `chain` is 3 x 65 int16
+// of LDS scratch. The probed bin sequence depends only on the two bins, not on a ray; the reference's result is an
+// OR over the probes, so neither probe order nor duplicates matter.
+// ------------------------------------------------------------------------------------------------------------
+__device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, const par_frame_dyn& dyn,
+                         int sx, int sy, int sz, int16_t (*chain)[65], par_slot* stage) {
+    const int lane = threadIdx.x & 63;
+    const int b0 = flat_index(g.gy, g.gz, sx, sy, sz);  // alt:430
+    // alt:406-430
+    const float fsx = (float)sx, fsy = (float)sy, fsz = (float)sz;
+    const float ddx = (float)dyn.lbx - fsx, ddy = (float)dyn.lby - fsy, ddz = (float)dyn.lbz - fsz;
+    float largest = __builtin_fabsf(ddx);
+    if (largest < __builtin_fabsf(ddy)) largest = __builtin_fabsf(ddy);
+    if (largest < __builtin_fabsf(ddz)) largest = __builtin_fabsf(ddz);
+    const int m = (int)largest;  // alt:432
+    const float step_mine = ((lane == 0) ? ddx : ((lane == 1) ? ddy : ddz)) / largest;  // alt:423-425
+    float carry = (lane == 0) ? fsx : ((lane == 1) ? fsy : fsz);
+    int n_rec = 0;
+    for (int it0 = 0; it0 < m; it0 += 64) {
+        const int n_it = min(64, m - it0);
+        if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
+            float v = carry;
+            chain[lane][0] = (int16_t)(int)v;  // alt:468
+            for (int q = 1; q <= n_it; q++) {
+                v = v + step_mine;
+                chain[lane][q] = (int16_t)(int)v;
+            }
+            carry = v;
+        }
+        // written and read by the same wavefront: LDS operations of one wavefront complete in order; keep the
+        // compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // lane l takes walk iteration it0 + l: its 7 probes (alt:438-466) are the corners of the 2x2x2 block
+        // spanned by bin(tmp) and bin(tmp + step), minus bin(tmp) itself
+        int idx[7], cnt[7];
+        int mine = 0;
+        {
+            const int li = min(lane, n_it - 1);
+            const int ax = chain[0][li], ay = chain[1][li], az = chain[2][li];
+            const int qx = chain[0][li + 1], qy = chain[1][li + 1], qz = chain[2][li + 1];
+            bool ok[7];
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                const int mask = q + 1;
+                // a probe whose stepped axes do not all change bin repeats another probe
+                const bool canonical = (!(mask & 1) || qx != ax) && (!(mask & 2) || qy != ay) &&
+                                       (!(mask & 4) || qz != az);
+                const int b = flat_index(g.gy, g.gz, (mask & 1) ? qx : ax, (mask & 2) ? qy : ay,
+                                         (mask & 4) ? qz : az);
+                // alt:471-473: the start bin is skipped; an out-of-range flat index reads as an empty bin (alt:476)
+                ok[q] = lane < n_it && canonical && b != b0 && b >= 0 && b < g.volume;
+                idx[q] = ok[q] ? b : 0;
+            }
+            // the seven counts are loaded side by side (no branch between the loads)
+#pragma unroll
+            for (int q = 0; q < 7; q++) cnt[q] = count[idx[q]];
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                cnt[q] = ok[q] ? cnt[q] : 0;
+                mine += cnt[q];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int incl = wave_incl_scan_i(mine, lane);
+        const int wave_total = __shfl(incl, 63);
+        if (n_rec + wave_total > PAR_BIN_WALK) return -1;
+        int o = n_rec + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            for (int k = 0; k < cnt[q]; k++) stage[o++] = slots[(size_t)idx[q] * PAR_SLOTS + k];
+        }
+        n_rec += wave_total;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return n_rec;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // columns_kernel: one workgroup (4 wavefronts) per occupied screen column (bx, by).
 //   A. the column's bins, front to back: compact list of the occupied ones and their slot records;
 //   B. one wavefront per occupied bin walks from it to the light as trace_hash_for_light does (alt:399-500). The
@@ -301,6 +386,20 @@ struct ColShared {
 __global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render_args a) {
     __shared__ ColShared sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the last gx workgroups (when background rays are traced) walk from the background start bins instead
+    const int n_col_blocks = (int)gridDim.x - (a.trace_bg ? g.gx : 0);
+    if ((int)blockIdx.x >= n_col_blocks) {
+        if (wave == 0) {
+            const int bx = (int)blockIdx.x - n_col_blocks;
+            const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+            // world (x, 0, 0): ray_bin = (x / B, (H - 0 - 0) / B, 0), alt:724-727
+            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, a.H / a.B, 0, sm.chain[0], sm.stage[0]);
+            par_bgwalk* out = g.bgwalk + bx;
+            for (int r = lane; r < n_rec; r += 64) out->rec[r] = sm.stage[0][r];
+            if (lane == 0) out->cnt = n_rec;
+        }
+        return;
+    }
     const int ci = (int)blockIdx.x;
     stamp(g, 0, 0);
     // the launch is sized by an upper bound of the occupied columns; both loads are issued together
@@ -355,81 +454,9 @@ __global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render
         int16_t(*chain)[65] = sm.chain[wave];
         par_slot* stage = sm.stage[wave];
         for (int i = wave; i < n_nb; i += 4) {  // wave-uniform
-            const int sx = bx, sy = by, sz = sm.nb[i].bz;
-            const int b0 = col_base + sz;
-            // alt:406-430
-            const float fsx = (float)sx, fsy = (float)sy, fsz = (float)sz;
-            const float ddx = (float)dyn.lbx - fsx, ddy = (float)dyn.lby - fsy, ddz = (float)dyn.lbz - fsz;
-            float largest = __builtin_fabsf(ddx);
-            if (largest < __builtin_fabsf(ddy)) largest = __builtin_fabsf(ddy);
-            if (largest < __builtin_fabsf(ddz)) largest = __builtin_fabsf(ddz);
-            const int m = (int)largest;  // alt:432
-            const float step_mine = ((lane == 0) ? ddx : ((lane == 1) ? ddy : ddz)) / largest;  // alt:423-425
-            float carry = (lane == 0) ? fsx : ((lane == 1) ? fsy : fsz);
-            int n_rec = 0;
-            bool w_over = false;
-            for (int it0 = 0; it0 < m && !w_over; it0 += 64) {
-                const int n_it = min(64, m - it0);
-                if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
-                    float v = carry;
-                    chain[lane][0] = (int16_t)(int)v;  // alt:468
-                    for (int q = 1; q <= n_it; q++) {
-                        v = v + step_mine;
-                        chain[lane][q] = (int16_t)(int)v;
-                    }
-                    carry = v;
-                }
-                // written and read by the same wavefront: LDS operations of one wavefront complete in order; keep
-                // the compiler from moving the reads above the writes
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-                // lane l takes walk iteration it0 + l: its 7 probes (alt:438-466) are the corners of the 2x2x2
-                // block spanned by bin(tmp) and bin(tmp + step), minus bin(tmp) itself
-                int idx[7], cnt[7];
-                int mine = 0;
-                {
-                    const int li = min(lane, n_it - 1);
-                    const int ax = chain[0][li], ay = chain[1][li], az = chain[2][li];
-                    const int qx = chain[0][li + 1], qy = chain[1][li + 1], qz = chain[2][li + 1];
-                    bool ok[7];
-#pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        const int mask = q + 1;
-                        // a probe whose stepped axes do not all change bin repeats another probe
-                        const bool canonical = (!(mask & 1) || qx != ax) && (!(mask & 2) || qy != ay) &&
-                                               (!(mask & 4) || qz != az);
-                        const int b = flat_index(g.gy, g.gz, (mask & 1) ? qx : ax, (mask & 2) ? qy : ay,
-                                                 (mask & 4) ? qz : az);
-                        // alt:471-473: the start bin is skipped; an out-of-range flat index reads as an empty bin
-                        // (alt:476)
-                        ok[q] = lane < n_it && canonical && b != b0 && b >= 0 && b < g.volume;
-                        idx[q] = ok[q] ? b : b0;
-                    }
-                    // the seven counts are loaded side by side (no branch between the loads)
-#pragma unroll
-                    for (int q = 0; q < 7; q++) cnt[q] = a.count[idx[q]];
-#pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        cnt[q] = ok[q] ? cnt[q] : 0;
-                        mine += cnt[q];
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const int incl = wave_incl_scan_i(mine, lane);
-                const int wave_total = __shfl(incl, 63);
-                if (n_rec + wave_total > PAR_BIN_WALK) {
-                    w_over = true;
-                } else {
-                    int o = n_rec + incl - mine;
-#pragma unroll
-                    for (int q = 0; q < 7; q++) {
-                        for (int k = 0; k < cnt[q]; k++) stage[o++] = a.slots[(size_t)idx[q] * PAR_SLOTS + k];
-                    }
-                    n_rec += wave_total;
-                }
-            }
+            const int sz = sm.nb[i].bz;
+            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, chain, stage);
+            const bool w_over = n_rec < 0;
             // reserve this bin's part of the column's walk area and copy the staged records out
             int woff = 0;
             if (lane == 0 && !w_over) woff = atomicAdd(&sm.n_walk, n_rec);
@@ -494,6 +521,43 @@ __global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render
     stamp(g, 0, 4);
 }
 
+__device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, int sx, int sy,
+                                 int sz, const par_frame_dyn& dyn, int self, int ox, int oy, int oz, float ix,
+                                 float iy, float iz);
+
+// ------------------------------------------------------------------------------------------------------------
+// bgline_kernel: the shadow ray of the background pixels of screen column x (alt:704-742 for a texel with normal 0,
+// y = z = 0, entity_index 0). It is the same ray for every row, so it is traced once per x; fill_kernel copies the
+// result into the `lit` plane. (The colour of a background pixel does not depend on it, SURVEY a-6.)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bgline_kernel(par_grid_dev g, par_render_args a) {
+    const int x = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (x >= a.W) return;
+    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+    // towards_light = normalize_L1(light - (x, 0, 0)), alt:711-715 + spr:28-35
+    const float dx = (float)(dyn.lx - x), dy = (float)(dyn.ly - 0), dz = (float)(dyn.lz - 0);
+    const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
+    const float tx = dx / len, ty = dy / len, tz = dz / len;
+    const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
+    const int ox = (int)(int16_t)x;                                    // alt:720-722
+    const int bx = div_bin(x, a.magic_b), sy = a.H / a.B;              // alt:724-727
+    bool lit = true;
+    const par_bgwalk* w = g.bgwalk + bx;
+    const int n = w->cnt;
+    if (n >= 0) {
+        for (int r = 0; r < n; r++) {
+            const par_slot rec = w->rec[r];
+            if (rec.entity != 0 && slab_hit(rec, ox, 0, 0, inv_x, inv_y, inv_z)) {  // self = entity 0, alt:484-491
+                lit = false;
+                break;
+            }
+        }
+    } else {
+        lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, 0, dyn, 0, ox, 0, 0, inv_x, inv_y, inv_z);
+    }
+    g.bglit[x] = lit ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // fill_kernel: background for every pixel of the row range. A pixel no primitive covers is {127,127,127,0}
 // (alt:281) times ambient (alt:735); its palette index is "none". The render kernels overwrite the tiles
@@ -503,7 +567,7 @@ __global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render
 // Requires W % 8 == 0 and 16-byte aligned planes; otherwise fill_generic_kernel runs.
 // ------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t out_rgba) {
+__global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t out_rgba, const uint8_t* bglit) {
     const int W = a.W;
     const int rows = a.row_end - a.row_begin;
     const int cpr = (W + 511) >> 9;  // 512-pixel chunks per row
@@ -529,12 +593,16 @@ __global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t o
             const int x = x0 + lane * 8;
             if (x < W) *reinterpret_cast<uint2*>(a.out.palidx + rowbase + x) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         }
+        if (a.out.lit) {  // the background ray of column x, traced once by bgline_kernel
+            const int x = x0 + lane * 8;
+            if (x < W) *reinterpret_cast<uint2*>(a.out.lit + rowbase + x) = *reinterpret_cast<const uint2*>(bglit + x);
+        }
     }
 }
 
 // Any plane, any geometry: one pixel per thread (parity / debugging planes and odd view sizes).
 __global__ __launch_bounds__(256) void fill_generic_kernel(par_render_args a, uint32_t out_rgba, int do_fb,
-                                                            int do_pal) {
+                                                            int do_pal, int do_lit, const uint8_t* bglit) {
     const long long npix = (long long)(a.row_end - a.row_begin) * a.W;
     par_pixel px;
     px.normal = par_vec3{0.f, 0.f, 0.f};
@@ -547,6 +615,7 @@ __global__ __launch_bounds__(256) void fill_generic_kernel(par_render_args a, ui
         if (do_pal && a.out.palidx) a.out.palidx[p] = PAR_PALIDX_BACKGROUND;
         if (a.out.brightness) a.out.brightness[p] = a.ambient;
         if (a.out.gbuf) a.out.gbuf[p] = px;
+        if (do_lit && a.out.lit) a.out.lit[p] = bglit[p % a.W];
     }
 }
 
@@ -767,7 +836,8 @@ __global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, 
             float nx = 0.f, ny = 0.f, nz = 0.f;
             uint32_t rgba = bg_rgba;
             int pal_index = PAR_PALIDX_BACKGROUND;
-            float bright = ambient;  // background: min(1, max(0, 0*t) + ambient) either way (SURVEY a-6); ray skipped
+            float bright = ambient;
+            bool lit_px = true;
             if (hit && !(a.flags & (1u << 26))) {  // bit 26: ablation (timing experiments only), no shading
                 // normal (alt:349-350) + resolved palette colour (alt:352-354)
                 const par_texel ti = (p_tex < PAR_SPRITE_TEXELS) ? sm.texinfo[p_tex] : a.texinfo[p_tex];
@@ -815,6 +885,7 @@ __global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, 
                                            inv_z);
                 }
                 bright = lit ? b_lit : ambient;
+                lit_px = lit;
             }
             if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
                 const unsigned long long m = __ballot(valid && hit);
@@ -824,11 +895,12 @@ __global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, 
             // ---- quantise + store, alt:735, 757-758 ------------------------------------------------------------
             if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
                 asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
-            } else if (valid) {
+            } else if (valid && hit) {  // (uncovered pixels keep what fill_kernel wrote)
                 const size_t o = (size_t)(row - a.row_begin) * W + col;
                 if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
                 if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
                 if (a.out.brightness) a.out.brightness[o] = bright;
+                if (a.out.lit) a.out.lit[o] = lit_px ? 1 : 0;
                 if (a.out.gbuf) {
                     par_pixel pxl;
                     pxl.normal = par_vec3{nx, ny, nz};
@@ -1247,9 +1319,14 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
                               hipStream_t stream) {
     if (a.dense) return hipSuccess;
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
-    const int64_t blocks = column_bound < cols_in_range ? column_bound : cols_in_range;
+    int64_t blocks = column_bound < cols_in_range ? column_bound : cols_in_range;
+    if (blocks < 0) blocks = 0;
+    if (a.trace_bg) blocks += g.gx;  // the background walks
     if (blocks <= 0) return hipSuccess;
     hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !a.trace_bg) return e;
+    hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
     return hipGetLastError();
 }
 
@@ -1261,23 +1338,26 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
     const int64_t npix = (int64_t)(a.row_end - a.row_begin) * a.W;
     const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
     const bool pal_fast = a.out.palidx && (a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0);
-    if (fb_fast || pal_fast) {
+    const bool lit_fast = a.out.lit && (a.W % 8 == 0) && ((uintptr_t)a.out.lit % 8 == 0);
+    if (fb_fast || pal_fast || lit_fast) {
         par_render_args f = a;
         if (!fb_fast) f.out.fb = nullptr;
         if (!pal_fast) f.out.palidx = nullptr;
+        if (!lit_fast) f.out.lit = nullptr;
         const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
         int64_t blocks = (chunks + 3) / 4;  // 4 wavefronts per block, one 512-pixel chunk each per iteration
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f, out_rgba);
+        hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f, out_rgba, g.bglit);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    const bool need_generic = (a.out.fb && !fb_fast) || (a.out.palidx && !pal_fast) || a.out.brightness || a.out.gbuf;
+    const bool need_generic = (a.out.fb && !fb_fast) || (a.out.palidx && !pal_fast) || (a.out.lit && !lit_fast) ||
+                              a.out.brightness || a.out.gbuf;
     if (need_generic) {
         int64_t blocks = (npix + 255) / 256;
         if (blocks > 16384) blocks = 16384;
         hipLaunchKernelGGL(fill_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, out_rgba,
-                           fb_fast ? 0 : 1, pal_fast ? 0 : 1);
+                           fb_fast ? 0 : 1, pal_fast ? 0 : 1, lit_fast ? 0 : 1, g.bglit);
         return hipGetLastError();
     }
     return hipSuccess;

@@ -171,3 +171,64 @@ def test_host_demo_binary(par, oracle, T, tmp_path):
         rgb = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(-1, 3)
         assert np.array_equal(rgb[:, 0], fb["red"]) and np.array_equal(rgb[:, 1], fb["green"]) and \
             np.array_equal(rgb[:, 2], fb["blue"]), f"frame {f}"
+
+
+def test_generic_kernel_on_every_tile(tmp_path):
+    """PAR_FORCE_GENERIC=1 sends every tile through the self-contained generic kernel (in-kernel group walks): the
+    path overflowed columns take. Run in a fresh process (the switch is read once) and compare with the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import importlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+par = importlib.import_module("pixel-art-raytracer_amd"); T = par.types
+from oracle.oracle import Oracle
+o = Oracle(); sprite = par.tile_floor()
+ALL = ("fb", "gbuf", "palidx", "brightness", "lit")
+for (w, h, l, n, seed) in [(480, 320, 320, 300, 5), (512, 512, 512, 64, 12345), (500, 333, 290, 200, 1)]:
+    params = T.default_params(w, h, l)
+    aabbs, light = par.scene_synthetic(n, w, h, l, seed)
+    exp = o.render(params, aabbs, sprite, light)
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        for planes in (ALL, ("fb", "palidx", "brightness", "gbuf")):
+            out = r.render(planes)
+            for k in planes:
+                assert out[k].tobytes() == exp[k].tobytes(), (w, h, k)
+aab = par.scene_graybox(); light = T.make_light(480, 160, 80); params = T.default_params()
+exp = o.render(params, aab, sprite, light)
+with par.Renderer(params) as r:
+    r.set_scene(aab, sprite, light)
+    out = r.render(ALL)
+    for k in ALL:
+        assert out[k].tobytes() == exp[k].tobytes(), k
+print("generic ok")
+''' % root
+    env = dict(os.environ, PAR_FORCE_GENERIC="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "generic ok" in p.stdout, p.stderr[-3000:]
+
+
+def test_every_ray_traced_mode(par, oracle, sprite, T):
+    """PAR_RENDER_TRACE_BACKGROUND without a lit plane, and the lit plane at full size: background rays included,
+    the lit mask equals the oracle's (trace_hash_for_light for every pixel, alt:703-742)."""
+    import os
+    w, h, l = 2048, 2048, 2048
+    params = T.default_params(w, h, l)
+    aabbs, light = par.scene_synthetic(256, w, h, l, 12345)
+    # a wall of boxes between most of the background and the light, so that many background rays are blocked
+    wall = T.make_aabbs([(1200 + 20 * (i % 3), 20 * j, 20 * k, 20, 20, 20) for i in range(3) for j in range(40)
+                         for k in range(0, 100, 2)])
+    aabbs = np.concatenate([aabbs, wall])
+    exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb", "lit"))
+    assert 0.02 < 1.0 - exp["lit"].mean() < 0.98  # both lit and shadowed pixels exist
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        out = r.render(("fb", "lit"))
+        assert out["lit"].tobytes() == exp["lit"].tobytes()
+        assert out["fb"].tobytes() == exp["fb"].tobytes()
+        out2 = r.render(("fb",), flags=par.RENDER_TRACE_BACKGROUND)
+        assert out2["fb"].tobytes() == exp["fb"].tobytes()
