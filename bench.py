@@ -116,13 +116,15 @@ def main():
 
     def step(i, flags=0):
         slot = pipe.slot(i)
-        with torch.cuda.stream(slot.stream):
-            if slot.pending is not None:  # the gather that last read this slot's block buffer
+        if gather is None:
+            pipe.submit(i, flags)
+            return
+        with torch.cuda.stream(slot.stream):  # the collective is ordered after the render on the slot's stream
+            if slot.pending is not None:      # the gather that last read this slot's block buffer
                 slot.pending.wait()
                 slot.pending = None
             pipe.submit(i, flags)
-            if gather is not None:
-                slot.pending = gather.gather(slot.buffers["fb"], async_op=True)
+            slot.pending = gather.gather(slot.buffers["fb"], async_op=True)
 
     def drain():
         for slot in pipe.slots:

@@ -165,6 +165,7 @@ class Renderer:
         if rc != PAR_OK:
             raise ParError(rc, lib().par_status_string(rc).decode())
         self.width, self.height = self.params.width, self.params.height
+        self._out_cache = {}
 
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
@@ -230,7 +231,13 @@ class Renderer:
         """Asynchronous render into device memory. `device_ptrs` maps plane name -> raw device pointer (int) that
         addresses (row_begin, 0). `stream` is a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream)."""
         r0, r1 = rows or (0, self.height)
-        o = Outputs(*[device_ptrs.get(k) for k in _PLANES])
+        # (the Outputs struct of a pointer set is cached: this is the per-frame call of a render loop)
+        key = id(device_ptrs)
+        cached = self._out_cache.get(key)
+        if cached is None or cached[0] is not device_ptrs:
+            cached = (device_ptrs, Outputs(*[device_ptrs.get(k) for k in _PLANES]))
+            self._out_cache[key] = cached
+        o = cached[1]
         if timed:
             st = FrameStats()
             self._check(lib().par_render_device_timed(self._ctx, C.c_void_p(stream), r0, r1, C.byref(o), flags,

@@ -232,3 +232,71 @@ def test_every_ray_traced_mode(par, oracle, sprite, T):
         assert out["fb"].tobytes() == exp["fb"].tobytes()
         out2 = r.render(("fb",), flags=par.RENDER_TRACE_BACKGROUND)
         assert out2["fb"].tobytes() == exp["fb"].tobytes()
+
+
+def test_edge_views_and_lights(par, oracle, sprite, T):
+    """Odd view sizes (width not a multiple of 8: the generic fill path; views smaller than a bin), empty scenes,
+    lights outside the view volume in every direction (out-of-range and aliased flat bin indices, SURVEY a-4),
+    a light inside a primitive, a light in the start bin (zero-length walk)."""
+    cases = [
+        (123, 77, 91, 60, 1, (60, 40, 20)),
+        (37, 29, 33, 25, 2, (10, 10, 10)),          # smaller than one bin
+        (481, 321, 321, 200, 3, (481, 160, 80)),    # light bin-x == grid width (the reference's default case)
+        (480, 320, 320, 300, 4, (-300, 500, -200)),
+        (480, 320, 320, 300, 5, (900, -400, 700)),
+        (480, 320, 320, 300, 6, (240, 160, 5000)),
+        (480, 320, 320, 0, 7, (240, 160, 80)),      # empty scene
+        (640, 200, 400, 250, 8, (0, 0, 0)),
+    ]
+    for (w, h, l, n, seed, lpos) in cases:
+        params = T.default_params(w, h, l)
+        aabbs, _ = par.scene_synthetic(n, w, h, l, seed)
+        light = T.make_light(*lpos)
+        exp = oracle.render(params, aabbs, sprite, light)
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            assert_planes_equal(r.render(ALL), exp, ALL, f"{w}x{h} light {lpos}")
+            fast = r.render(("fb", "palidx", "brightness", "gbuf"))
+            assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"{w}x{h} light {lpos} fast")
+    # light exactly on primitives' planes and in their bins: zero light-vector components -> inf/NaN slabs (a-5)
+    params = T.default_params()
+    rows = [(i * 20, 0, j * 20, 20, 20, 20) for i in range(24) for j in range(16)]
+    rows += [(200, 20, 100, 20, 20, 20), (220, 40, 100, 20, 20, 20), (200, 20, 140, 20, 20, 20)]
+    aabbs = T.make_aabbs(rows)
+    for lpos in [(210, 40, 110), (200, 20, 100), (240, 20, 100), (210, 30, 110), (0, 20, 0)]:
+        light = T.make_light(*lpos)
+        exp = oracle.render(params, aabbs, sprite, light)
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            assert_planes_equal(r.render(ALL), exp, ALL, f"light on planes {lpos}")
+
+
+def test_config5_scale_animation(par, oracle, sprite, T):
+    """BASELINE config 5 at its own size: 1024x1024, 512 moving primitives, hipGraph replay per frame (a sample of
+    frames checked against the oracle; positions keep moving by the reference's step of 5, alt:643-678)."""
+    import os
+    import torch
+    w = h = l = 1024
+    n = 512
+    params = T.default_params(w, h, l)
+    aabbs, light = par.scene_synthetic(n, w, h, l, 99)
+    rng = np.random.default_rng(11)
+    vel = rng.choice([-5, 0, 5], size=(n, 3)).astype(np.int16)
+    fb = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        r.graph_capture({"fb": fb.data_ptr()}, stream=stream.cuda_stream)
+        for f in range(40):
+            if f:
+                aabbs["px"] += vel[:, 0]
+                aabbs["py"] += vel[:, 1]
+                aabbs["pz"] += vel[:, 2]
+                if f % 7 == 0:
+                    light["z"] += 5
+                r.graph_stage(aabbs, 0, light)
+            r.graph_launch(stream.cuda_stream)
+            if f % 8 == 0 or f == 39:
+                stream.synchronize()
+                exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb",))
+                assert np.array_equal(fb.cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
