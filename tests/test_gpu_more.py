@@ -300,3 +300,16 @@ def test_config5_scale_animation(par, oracle, sprite, T):
                 stream.synchronize()
                 exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb",))
                 assert np.array_equal(fb.cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
+
+
+def test_config1_default_scene_128(par, oracle, sprite, T):
+    """BASELINE config 1: 128x128 view of the reference's default graybox world (alt:517-599 parameterised on the
+    view), light at (W, H/2, L/4) as alt:625-626 (its bin-x equals the grid width: the out-of-range case)."""
+    params = T.default_params(128, 128, 128)
+    aabbs = par.scene_graybox(128, 128)
+    light = T.make_light(128, 64, 32)
+    exp = oracle.render(params, aabbs, sprite, light)
+    assert (exp["palidx"] != T.PALIDX_BACKGROUND).mean() > 0.5
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        assert_planes_equal(r.render(ALL), exp, ALL, "128x128 graybox")
