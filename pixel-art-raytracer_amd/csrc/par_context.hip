@@ -27,6 +27,8 @@ struct par_context {
     bool have_light = false, have_entities = false;
     par_light light{};
     int set = 0;  // head/count/node set the NEXT frame uses
+    hipStream_t last_stream = nullptr;  // stream of the most recent asynchronous render (scene updates wait for it)
+    bool has_last_stream = false;
 
     // device
     par_aabb* d_aabbs = nullptr;
@@ -563,7 +565,8 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     PAR_HIP(hipSetDevice(ctx->device));
     int rc = ensure_pool(ctx, total);
     if (rc != PAR_OK) return rc;
-    // stream-ordered behind any frame still in flight on the context stream
+    // a frame enqueued asynchronously by par_render_device may still be reading the AABBs: wait for it
+    if (ctx->has_last_stream) PAR_HIP(hipStreamSynchronize(ctx->last_stream));
     PAR_HIP(hipMemcpyAsync(ctx->d_aabbs + first, aabbs, (size_t)n * sizeof(par_aabb), hipMemcpyHostToDevice, ctx->stream));
     PAR_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; i++) {
@@ -601,6 +604,8 @@ int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end
     if (rc != PAR_OK) return rc;
     ctx->set ^= 1;
     ctx->last_flags = flags;
+    ctx->last_stream = (hipStream_t)stream;
+    ctx->has_last_stream = true;
     return PAR_OK;
 }
 
