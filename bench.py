@@ -68,14 +68,19 @@ def cpu_baseline(par, T, params, aabbs, light, sprite, rows):
 
 
 def main():
+    global W, H, L
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight (contexts/streams/buffers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests)")
+    ap.add_argument("--share-gpu", action="store_true", help="tests: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--size", type=int, default=W, help="tests: view size (the benchmark is 4096)")
     args = ap.parse_args()
 
+    W = H = L = args.size
     import torch
     import torch.distributed as dist
 
@@ -87,10 +92,15 @@ def main():
                          "--nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     par = importlib.import_module("pixel-art-raytracer_amd")
     T = par.types
@@ -172,7 +182,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -182,12 +192,12 @@ def main():
         rays_per_frame = 2.0 * W * H
         value = rays_per_frame * args.steps / elapsed / 1e6
         out = {
-            "metric": "Mrays/sec at 4096x4096, 1024 prims", "value": round(value, 1), "unit": "Mrays/s",
+            "metric": f"Mrays/sec at {W}x{H}, {N_PRIMS} prims", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32+f32",
             "data": "synthetic",
-            "config": {"workload": "4096x4096x4096 view, bin 40, 1024 primitives (splitmix64 seed 12345), "
-                                   "light (2560,2048,1024); RGBA8 frame + palette-index plane",
+            "config": {"workload": f"{W}x{H}x{L} view, bin 40, {N_PRIMS} primitives (splitmix64 seed {SEED}), "
+                                   f"light ({5 * W // 8},{H // 2},{L // 4}); RGBA8 frame + palette-index plane",
                        "sharding": f"row blocks over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
                        "frames_in_flight": depth},
             "frames_per_s": round(args.steps / elapsed, 1),

@@ -21,6 +21,13 @@ def max_block_rows(world, height):
     return max(row_block(r, world, height)[1] - row_block(r, world, height)[0] for r in range(world))
 
 
+class _Done:
+    """A completed work handle."""
+
+    def wait(self):
+        return True
+
+
 class FrameGather:
     """Assembles row blocks on `dst`. With equal blocks the root receives straight into views of the final frame
     (no staging copy); otherwise blocks are padded to the largest one and unpacked on the root."""
@@ -49,6 +56,8 @@ class FrameGather:
     def gather(self, block, async_op=False):
         """`block`: this rank's padded block buffer. Returns the work handle when async_op, else None; the assembled
         frame is `self.frame` on the root."""
+        if block.is_cuda and dist.get_backend(self.group) == "gloo":
+            return self._gather_via_host(block)
         glist = None
         if self.rank == self.dst:
             if self.equal:
@@ -60,6 +69,22 @@ class FrameGather:
         if not async_op:
             self.unpack()
         return work
+
+    def _gather_via_host(self, block):
+        """Test path (gloo has no device gather): the same exchange staged through host memory, synchronously. Lets
+        the N > 1 control flow of bench.py be exercised where RCCL cannot run (several ranks sharing one GPU)."""
+        torch.cuda.current_stream().synchronize()
+        host = block.cpu()
+        glist = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+        dist.gather(host, glist, dst=self.dst, group=self.group)
+        if self.rank == self.dst:
+            n = self.max_rows * self.row_elems
+            for r, t in enumerate(glist):
+                if self.equal:
+                    self.frame[r * n:(r + 1) * n].copy_(t)
+                else:
+                    self.staging[r].copy_(t)
+        return _Done()
 
     def unpack(self):
         """Uneven blocks only: copy the padded staging buffers into the frame (after the gather completed)."""

@@ -313,3 +313,29 @@ def test_config1_default_scene_128(par, oracle, sprite, T):
     with par.Renderer(params) as r:
         r.set_scene(aabbs, sprite, light)
         assert_planes_equal(r.render(ALL), exp, ALL, "128x128 graybox")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multi_rank_control_flow(world):
+    """bench.py's N > 1 path (row blocks, frames in flight, per-frame gather, verification of the assembled frame)
+    with `world` ranks sharing the one GPU of the test box. RCCL cannot run several ranks on one device, so the
+    exchange goes through gloo here; everything else is the code the 8-GPU run executes."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+           "--gpus", str(world), "--steps", "12", "--warmup", "3", "--backend", "gloo", "--share-gpu",
+           "--size", "1000" if world == 3 else "1024", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == world and d["steps"] == 12 and d["verified_vs_single_gpu_frame"] is True
+    assert d["value"] > 0 and d["scaling"] == "strong"
