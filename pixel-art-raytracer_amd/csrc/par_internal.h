@@ -60,6 +60,7 @@ struct par_colrec {
     par_slot walk[PAR_COL_WALK];
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
+constexpr int PAR_COL_WAVES = 2;         // wavefronts per columns_kernel workgroup (one shadow walk each at a time)
 constexpr int PAR_MAX_SUBS = 96;  // tiles per column the cover mask can describe
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world

@@ -359,7 +359,7 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// columns_kernel: one workgroup (4 wavefronts) per occupied screen column (bx, by).
+// columns_kernel: one workgroup (PAR_COL_WAVES wavefronts) per occupied screen column (bx, by).
 //   A. the column's bins, front to back: compact list of the occupied ones and their slot records;
 //   B. one wavefront per occupied bin walks from it to the light as trace_hash_for_light does (alt:399-500). The
 //      probed bin sequence depends only on the start and light bins, not on the ray, so it is done ONCE per bin
@@ -375,15 +375,15 @@ struct ColShared {
     par_colrec_nb nb[PAR_COL_NB];
     par_slot entries[PAR_COL_ENT];
     int16_t ebz[PAR_COL_ENT];
-    par_slot stage[4][PAR_BIN_WALK];  // per wavefront: the records of the walk it is doing
-    int16_t chain[4][3][65];
-    int32_t wsum[4];
+    par_slot stage[PAR_COL_WAVES][PAR_BIN_WALK];  // per wavefront: the records of the walk it is doing
+    int16_t chain[PAR_COL_WAVES][3][65];
+    int32_t wsum[PAR_COL_WAVES];
     int32_t n_walk;
     int32_t overflow;
     int32_t tile_mode;
 };
 
-__global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render_args a) {
+__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a) {
     __shared__ ColShared sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the last gx workgroups (when background rays are traced) walk from the background start bins instead
@@ -417,12 +417,12 @@ __global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render
     // ---- A: ordered compaction of the column ------------------------------------------------------------------
     int nb_base = 0, ent_base = 0;
     bool over = false;
-    for (int t0 = 0; t0 < g.gz; t0 += 256) {
+    for (int t0 = 0; t0 < g.gz; t0 += PAR_COL_WAVES * 64) {
         const int t = t0 + tid;
         const par_slot* src = a.slots + (size_t)(col_base + min(t, g.gz - 1)) * PAR_SLOTS;
         const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;
         int total;
-        const int packed = block_excl_scan<4>(((c != 0) << 16) | c, sm.wsum, total);
+        const int packed = block_excl_scan<PAR_COL_WAVES>(((c != 0) << 16) | c, sm.wsum, total);
         const int nb_i = nb_base + (packed >> 16);
         const int off = ent_base + (packed & 0xFFFF);
         if (c != 0) {
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void columns_kernel(par_grid_dev g, par_render
         const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
         int16_t(*chain)[65] = sm.chain[wave];
         par_slot* stage = sm.stage[wave];
-        for (int i = wave; i < n_nb; i += 4) {  // wave-uniform
+        for (int i = wave; i < n_nb; i += PAR_COL_WAVES) {  // wave-uniform
             const int sz = sm.nb[i].bz;
             const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, chain, stage);
             const bool w_over = n_rec < 0;
@@ -1323,7 +1323,7 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
     if (blocks < 0) blocks = 0;
     if (a.trace_bg) blocks += g.gx;  // the background walks
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(PAR_COL_WAVES * 64), 0, stream, g, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !a.trace_bg) return e;
     hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
@@ -1346,7 +1346,9 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
         if (!lit_fast) f.out.lit = nullptr;
         const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
         int64_t blocks = (chunks + 3) / 4;  // 4 wavefronts per block, one 512-pixel chunk each per iteration
-        if (blocks > 8192) blocks = 8192;
+        // 2048 blocks (8 per CU) already run at full bandwidth (measured: 256 do); more only take wave slots from
+        // the other frames in flight
+        if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, f, out_rgba, g.bglit);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
