@@ -195,7 +195,6 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.tile_rows = PAR_NT / B;
     a.subs = c->grid.subs;
     a.set = set;
-    a.magic_tr = (uint32_t)((1ull << 32) / (uint64_t)a.tile_rows + 1ull);
     // every ray traced (as the reference does), or the lit plane requested
     a.trace_bg = ((flags & PAR_RENDER_TRACE_BACKGROUND) || out.lit) ? 1 : 0;
     // PAR_FORCE_GENERIC=1 (testing): every tile goes through the self-contained generic kernel
@@ -205,7 +204,6 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.ambient = c->params.ambient;
     a.background = c->params.background;
     a.flags = flags;
-    a.n_sprites = c->n_sprites;
     a.dyn = make_dyn(c, c->light);
     a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;
     a.count = c->grid.count[set];
@@ -376,10 +374,6 @@ int par_create(const par_params* params, int device, par_context** out) {
     {
         const int tr = PAR_NT / p.bin_size;
         ctx->grid.subs = (p.bin_size + tr - 1) / tr;
-    }
-    if (ctx->grid.subs > PAR_MAX_SUBS) {
-        par_destroy(ctx);
-        return PAR_ERR_UNSUPPORTED;
     }
     if ((e = hipMalloc(&ctx->grid.slow_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.bgwalk, (size_t)gx * sizeof(par_bgwalk))) != hipSuccess) return bail(e);

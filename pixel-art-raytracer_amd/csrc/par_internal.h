@@ -50,10 +50,10 @@ struct par_colrec_nb {
 };
 struct par_colrec {
     int16_t n_nb, n_entries, n_walk;
-    int16_t overflow;    // 1: the column does not fit this record; the generic kernel renders its tiles
+    int16_t overflow;    // 1: the column does not fit this record; the generic kernel renders it
     int32_t col;         // bx * gy + by
-    uint32_t cover[3];   // bit s: some record can cover a pixel of tile s of the column (and s is in the row range)
-    int32_t pad_[2];
+    int32_t tile_mode;   // 1: visit the column's pixels as whole tiles, 0: entry rectangle by entry rectangle
+    int32_t pad_[4];
     par_colrec_nb nb[PAR_COL_NB];
     int16_t ebz[PAR_COL_ENT];  // bin_z of each entry (the primary pass walks the entries as one flat list)
     par_slot entries[PAR_COL_ENT];
@@ -61,7 +61,6 @@ struct par_colrec {
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 constexpr int PAR_COL_WAVES = 2;         // wavefronts per columns_kernel workgroup (one shadow walk each at a time)
-constexpr int PAR_MAX_SUBS = 96;  // tiles per column the cover mask can describe
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world
 // position (x, 0, 0) (alt:281, 707-709), so its ray starts in bin (x / B, H / B, 0) whatever its row -- one walk per
@@ -122,11 +121,9 @@ struct par_render_args {
     float ambient;
     uint32_t background;           // gray level (alt:281)
     uint32_t flags;
-    int32_t n_sprites;
     par_frame_dyn dyn;             // used when dyn_ptr == nullptr
     const par_frame_dyn* dyn_ptr;  // graph path
     const uint8_t* count;
-    uint32_t magic_tr;             // floor(n / tile_rows) == __umulhi(n, magic_tr) for n < B
     const par_slot* slots;
     const par_sprite* sprites;
     const par_texel* texinfo;      // [n_sprites * 800]

@@ -506,8 +506,7 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_de
             rec->n_walk = (int16_t)sm.n_walk;
             rec->overflow = overflow ? 1 : 0;
             rec->col = col;
-            rec->cover[0] = sm.tile_mode;
-            rec->cover[1] = rec->cover[2] = 0;
+            rec->tile_mode = sm.tile_mode;
         }
         if (!overflow) {
             if (tid < n_nb) rec->nb[tid] = sm.nb[tid];
@@ -742,7 +741,7 @@ __global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, 
         //    pixel is rendered exactly once and the lanes of a pass are (nearly) all covered pixels; what no entry
         //    covers keeps the background fill_kernel wrote;
         //  - as whole tiles (own = -1) when the rectangles would add up to more than the column itself.
-        const bool tile_mode = rec_.cover[0] != 0;
+        const bool tile_mode = rec_.tile_mode != 0;
         const int n_pass = tile_mode ? 1 : n_entries;
         for (int q = tile_mode ? 0 : part; q < n_pass; q += tile_mode ? 1 : parts) {  // uniform
             const int own = tile_mode ? -1 : q;

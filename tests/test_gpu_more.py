@@ -339,3 +339,108 @@ def test_bench_multi_rank_control_flow(world):
     d = json.loads(line)
     assert d["n_gpus"] == world and d["steps"] == 12 and d["verified_vs_single_gpu_frame"] is True
     assert d["value"] > 0 and d["scaling"] == "strong"
+
+
+def test_host_demo_gif(par, oracle, T, tmp_path):
+    """The animated GIF the host program writes (frame sink replacing the SDL present): every frame decodes to
+    exactly the oracle's frame (each frame's colours fit one exact 256-entry local colour table)."""
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(par.LIB_PATH), "par_demo")
+    gif = tmp_path / "anim.gif"
+    p = subprocess.run([demo, "--keys", "RRUUhhjjPP", "--frames", "6", "--gif", str(gif), "--debug-line"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    frames = _decode_gif(gif.read_bytes())
+    assert len(frames) == 6
+    params = T.default_params()
+    aabbs = par.scene_graybox(480, 320)
+    light = T.make_light(480, 160, 80)
+    sprite = par.tile_floor()
+    from helpers import apply_key
+    for f in range(6):
+        if f:
+            apply_key("RRUUhhjjPP"[f - 1], aabbs, light)
+        out = oracle.render(params, aabbs, sprite, light, planes=("fb", "gbuf"))
+        fb = out["fb"]
+        oracle.debug_line(params, out["gbuf"], light, 0, 0, fb)
+        exp = np.stack([fb["red"], fb["green"], fb["blue"]], axis=1)
+        assert np.array_equal(frames[f], exp), f"frame {f}"
+
+
+def _decode_gif(data):
+    """Minimal GIF89a decoder (local colour tables, no interlace): list of (H*W, 3) uint8 arrays."""
+    assert data[:6] == b"GIF89a"
+    w, h = int.from_bytes(data[6:8], "little"), int.from_bytes(data[8:10], "little")
+    pos = 13
+    if data[10] & 0x80:
+        pos += 3 * (2 << (data[10] & 7))
+    frames = []
+    while True:
+        b = data[pos]
+        if b == 0x3B:
+            break
+        if b == 0x21:  # extension: skip sub-blocks
+            pos += 2
+            while data[pos]:
+                pos += 1 + data[pos]
+            pos += 1
+            continue
+        assert b == 0x2C
+        fw, fh = int.from_bytes(data[pos + 5:pos + 7], "little"), int.from_bytes(data[pos + 7:pos + 9], "little")
+        flags = data[pos + 9]
+        pos += 10
+        assert (fw, fh) == (w, h) and (flags & 0x80) and not (flags & 0x40)
+        n = 2 << (flags & 7)
+        table = np.frombuffer(data[pos:pos + 3 * n], dtype=np.uint8).reshape(n, 3)
+        pos += 3 * n
+        min_bits = data[pos]
+        pos += 1
+        stream = bytearray()
+        while data[pos]:
+            stream += data[pos + 1:pos + 1 + data[pos]]
+            pos += 1 + data[pos]
+        pos += 1
+        # LZW
+        clear, eoi = 1 << min_bits, (1 << min_bits) + 1
+        bits, nxt = min_bits + 1, eoi + 1
+        dict_ = {i: bytes([i]) for i in range(clear)}
+        out = bytearray()
+        acc = nacc = 0
+        prev = None
+        it = iter(stream)
+        done = False
+        while not done:
+            while nacc < bits:
+                try:
+                    acc |= next(it) << nacc
+                except StopIteration:
+                    done = True
+                    break
+                nacc += 8
+            if done:
+                break
+            code = acc & ((1 << bits) - 1)
+            acc >>= bits
+            nacc -= bits
+            if code == clear:
+                dict_ = {i: bytes([i]) for i in range(clear)}
+                bits, nxt, prev = min_bits + 1, eoi + 1, None
+                continue
+            if code == eoi:
+                break
+            if prev is None:
+                entry = dict_[code]
+            else:
+                entry = dict_[code] if code in dict_ else prev + prev[:1]
+                if nxt < 4096:
+                    dict_[nxt] = prev + entry[:1]
+                    nxt += 1
+                    if nxt == (1 << bits) and bits < 12:
+                        bits += 1
+            out += entry
+            prev = entry
+        idx = np.frombuffer(bytes(out[:w * h]), dtype=np.uint8)
+        assert len(idx) == w * h
+        frames.append(table[idx])
+    return frames
