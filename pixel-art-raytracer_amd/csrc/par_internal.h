@@ -51,7 +51,7 @@ struct par_colrec_nb {
 struct par_colrec {
     int16_t n_nb, n_entries, n_walk;
     int16_t overflow;    // 1: the column does not fit this record; the generic kernel renders it
-    int32_t col;         // bx * gy + by
+    int16_t bx, by;      // the column
     int32_t tile_mode;   // 1: visit the column's pixels as whole tiles, 0: entry rectangle by entry rectangle
     int32_t pad_[4];
     par_colrec_nb nb[PAR_COL_NB];

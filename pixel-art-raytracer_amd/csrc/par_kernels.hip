@@ -505,7 +505,8 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_de
             rec->n_entries = (int16_t)(overflow ? 0 : n_entries);
             rec->n_walk = (int16_t)sm.n_walk;
             rec->overflow = overflow ? 1 : 0;
-            rec->col = col;
+            rec->bx = (int16_t)bx;
+            rec->by = (int16_t)by;
             rec->tile_mode = sm.tile_mode;
         }
         if (!overflow) {
@@ -674,6 +675,7 @@ struct FastShared {
     par_texel texinfo[PAR_SPRITE_TEXELS];      // sprite 0: normal + resolved palette colour per texel
     int32_t sprite_depth[PAR_SPRITE_TEXELS];   // sprite 0: depth per texel (the hot lookup of the primary pass)
     uint8_t sprite_color[PAR_SPRITE_TEXELS];   // sprite 0: palette index per texel
+    uint32_t magic[PAR_MAX_BIN + 1];           // magic[w]: floor(p / w) == __umulhi(p, magic[w]) for p * w < 2^32
     int32_t next[2];                           // work items handed out by the group counter
 };
 
@@ -712,6 +714,8 @@ __global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, 
         sm.texinfo[t] = a.texinfo[t];
         sm.sprite_color[t] = (uint8_t)a.sprites[0].color[t];
     }
+    // rectangle widths are at most one bin: one division per width here instead of one per pass
+    for (int t = tid + 1; t <= PAR_MAX_BIN; t += PAR_NT) sm.magic[t] = (uint32_t)(0xFFFFFFFFu / (uint32_t)t) + 1u;
     stamp(g, 1, 1);
     for (int it = 0;; it++) {
         const int buf = it & 1;
@@ -729,8 +733,7 @@ __global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, 
         const par_colrec& rec_ = sm.rec[buf];
         const int n_entries = (rec_.overflow || (a.flags & (1u << 24))) ? 0 : rec_.n_entries;  // bit 24: ablation
         const int n_nb = rec_.n_nb;
-        const int col_id = rec_.col;
-        const int bx = col_id / g.gy, by = col_id - bx * g.gy;
+        const int bx = rec_.bx, by = rec_.by;
         const int c0 = bx * B;
         const int tw = min(B, W - c0);
         const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
@@ -766,8 +769,8 @@ __global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, 
             ry0 = __builtin_amdgcn_readfirstlane(ry0);
             rh = __builtin_amdgcn_readfirstlane(rh);
             if (rw <= 0 || rh <= 0) continue;
-            // floor(p / rw) == __umulhi(p, magic_w) for p * rw < 2^32; a 1-pixel-wide rectangle has no such multiplier
-            const uint32_t magic_w = (uint32_t)(0xFFFFFFFFu / (uint32_t)rw) + 1u;
+            // floor(p / rw) == __umulhi(p, magic_w); a 1-pixel-wide rectangle has no such multiplier
+            const uint32_t magic_w = sm.magic[rw];
             const int area = rw * rh;
             for (int base = 0; base < area; base += PAR_NT) {
             const int pidx = base + tid;
