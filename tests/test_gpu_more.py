@@ -444,3 +444,46 @@ def _decode_gif(data):
         assert len(idx) == w * h
         frames.append(table[idx])
     return frames
+
+
+def test_deep_grid_and_far_light(par, oracle, sprite, T):
+    """A grid 1000 bins deep (the per-column scans iterate) and lights thousands of bins away (walks far longer
+    than one staging pass; flat bin indices far outside the grid)."""
+    w, h, l, b = 96, 80, 8000, 8
+    params = T.default_params(w, h, l, b)
+    assert params.grid_dims() == (12, 10, 1000)
+    rng = np.random.default_rng(3)
+    n = 400
+    aabbs = np.zeros(n, dtype=T.AABB)
+    aabbs["px"] = rng.integers(-10, w, n)
+    aabbs["py"] = rng.integers(-30, 60, n)
+    aabbs["pz"] = rng.integers(-20, l, n)
+    aabbs["pz"][:150] = rng.integers(0, 120, 150)  # many near the front so that pixels are covered
+    aabbs["ex"] = rng.integers(1, 21, n)
+    aabbs["ey"] = rng.integers(0, 21, n)
+    aabbs["ez"] = rng.integers(0, 21, n)
+    for lpos in [(48, 40, 30000), (48, 30000, 60), (-20000, 10, 10), (50, 20, 4000)]:
+        light = T.make_light(*lpos)
+        exp = oracle.render(params, aabbs, sprite, light)
+        assert (exp["palidx"] != T.PALIDX_BACKGROUND).any()
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            assert_planes_equal(r.render(ALL), exp, ALL, f"deep grid light {lpos}")
+            fast = r.render(("fb", "palidx", "brightness", "gbuf"))
+            assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"deep grid light {lpos} fast")
+
+
+def test_dense_floor_full_size(par, oracle, sprite, T):
+    """4096x4096 covered by a full floor of 41 943 tiles (83 028 bin insertions: the node pool grows past its
+    initial size; every column is occupied; most columns are visited as whole tiles)."""
+    import os
+    w = h = l = 4096
+    params = T.default_params(w, h, l)
+    aabbs = T.make_aabbs([(i * 20, 0, j * 20, 20, 20, 20) for i in range(w // 20) for j in range(l // 20)])
+    light = T.make_light(2560, 2048, 1024)
+    exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb", "palidx"))
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        out = r.render(("fb", "palidx"))
+        assert r.stats().bin_insertions > 65536
+        assert out["fb"].tobytes() == exp["fb"].tobytes() and out["palidx"].tobytes() == exp["palidx"].tobytes()
