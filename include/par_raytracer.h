@@ -103,16 +103,21 @@ int par_set_light(par_context* ctx, const par_light* light);
 int par_render(par_context* ctx, const par_outputs* host_out, unsigned flags);
 /* Rows [row_begin,row_end) only (multi-GPU row-block sharding); host buffers, synchronous. */
 int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outputs* host_out, unsigned flags);
-/* Asynchronous: enqueue on `stream` (a hipStream_t, NULL = default stream) writing DEVICE buffers. No sync. */
+/* Asynchronous: enqueue on `stream` (a hipStream_t, NULL = default stream) writing DEVICE buffers. No sync.
+ * Several frames may be in flight at once, each on its own context and stream (a frame alone is a chain of short
+ * kernels that leaves most of the chip idle). A scene update (par_update_aabbs) waits for the context's last
+ * asynchronous frame first. */
 int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
                       unsigned flags);
-/* As par_render_device, bracketing the binning and render kernels with HIP events on `stream`; blocks until the
- * frame is done and fills stats->ms_bin / ms_render. */
+/* As par_render_device, bracketing the kernel groups with HIP events on `stream`; blocks until the frame is done
+ * and fills stats->ms_bin (hash build + column kernels) / ms_fill / ms_render (the two render kernels). */
 int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int row_end,
                             const par_outputs* device_out, unsigned flags, par_frame_stats* stats);
 
-/* hipGraph path (BASELINE config 5): capture {pinned-host AABB/light upload -> bin -> render} once, replay per
- * frame. `par_graph_stage` writes the next frame's AABBs/light into the pinned staging area the graph copies from. */
+/* hipGraph path (BASELINE config 5): capture {pinned-host AABB/light upload -> build -> fill -> render} once, replay
+ * per frame. `par_graph_stage` writes the next frame's AABBs/light into the pinned staging area the graph copies
+ * from; it fails with PAR_ERR_UNSUPPORTED when the staged scene needs larger launch grids than were captured (about
+ * twice the bin insertions of the captured frame): capture again then. */
 int par_graph_capture(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
                       unsigned flags);
 int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, const par_light* light);
