@@ -1383,7 +1383,11 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     // per-group counters, and the next record's load overlaps the current column's pixels.
     const int64_t cap = (int64_t)256 * 5;
     // (a column is split into up to 8 work items when there are fewer columns than resident workgroups)
-    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)(bound * 8 > cap ? cap : bound * 8)), dim3(PAR_NT), 0, stream, g, a);
+    // (a multiple of the group count: every group then has the same number of workgroups, which the fixed first two
+    // items of each workgroup rely on)
+    int64_t fast_blocks = bound * 8 > cap ? cap : bound * 8;
+    fast_blocks = (fast_blocks + PAR_SCHED_GROUPS - 1) / PAR_SCHED_GROUPS * PAR_SCHED_GROUPS;
+    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)fast_blocks), dim3(PAR_NT), 0, stream, g, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // overflowed columns are the exception: a small strided grid
