@@ -68,7 +68,7 @@ def cpu_baseline(par, T, params, aabbs, light, sprite, rows):
 
 
 def main():
-    global W, H, L
+    global W, H, L, N_PRIMS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -77,10 +77,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="tests: every rank uses GPU 0 (needs --backend gloo)")
-    ap.add_argument("--size", type=int, default=W, help="tests: view size (the benchmark is 4096)")
+    ap.add_argument("--size", type=int, default=W, help="view size (the headline benchmark is 4096; BASELINE config 3: 2048)")
+    ap.add_argument("--prims", type=int, default=N_PRIMS, help="primitives (headline 1024; BASELINE config 3: 256)")
     args = ap.parse_args()
 
     W = H = L = args.size
+    N_PRIMS = args.prims
     import torch
     import torch.distributed as dist
 

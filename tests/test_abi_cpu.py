@@ -83,3 +83,33 @@ def test_no_gpu_means_loud_failure(par, T):
     with pytest.raises(par.ParError) as e:
         par.Renderer(T.default_params())
     assert e.value.status == 2  # PAR_ERR_NO_DEVICE: there is no CPU rendering path
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h is a C ABI: it must compile as C11 (no C++), and a C program must link against the library."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "par_raytracer.h"
+int main(void) {
+    par_params p;
+    int gx, gy, gz;
+    par_default_params(&p);
+    if (par_grid_dims(&p, &gx, &gy, &gz) != PAR_OK) return 1;
+    par_sprite s;
+    par_sprite_tile_floor(&s);
+    printf("%d %d %d %d %zu %zu %zu %s\n", gx, gy, gz, s.depth[0], sizeof(par_pixel), sizeof(par_aabb),
+           sizeof(par_sprite), par_status_string(PAR_ERR_NO_DEVICE));
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    lib_dir = os.path.join(ROOT, "pixel-art-raytracer_amd", "lib")
+    p = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe), "-L", lib_dir, "-lpar_raytracer", f"-Wl,-rpath,{lib_dir}"],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0
+    assert out.stdout.split()[:7] == ["12", "8", "8", "19", "28", "16", "16000"]
