@@ -252,7 +252,18 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
     }
     if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
-    PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
+    // hash insert and background fill depend on nothing earlier in the frame: one launch for both when the fill is
+    // the plain streaming one (timed runs keep them apart so that the event pairs bracket single kernels)
+    bool filled = false;
+    if (!ev) {
+        const hipError_t e = par_launch_insert_fill(ctx->grid, b, r, stream);
+        if (e == hipSuccess) {
+            filled = true;
+        } else if (e != hipErrorNotSupported) {
+            return hip_fail(ctx, e, "par_launch_insert_fill");
+        }
+    }
+    if (!filled) PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
     // what par_graph_stage accepts (graph_pair_bound); beyond it the caller captures again.
     const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : ctx->total_pairs;
@@ -265,7 +276,7 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // slower, alone and with several frames in flight: the cross-stream events cost more than the overlap gains,
     // and frames in flight fill the idle CUs anyway.) It follows the column kernels because, when background rays
     // are traced, it copies their results into the lit plane.
-    PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    if (!filled) PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));

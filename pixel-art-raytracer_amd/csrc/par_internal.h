@@ -138,6 +138,9 @@ enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_SCHED = 8, PAR_CNT_TOTAL = PA
 
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
+// Hash insert + background fill in one launch when possible (else hipErrorNotSupported, nothing launched).
+hipError_t par_launch_insert_fill(const par_grid_dev& g, const par_bin_args& b, const par_render_args& a,
+                                  hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
 // Per occupied column: compact slot list, the shadow walks of its bins, and its tiles onto the work lists.
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);

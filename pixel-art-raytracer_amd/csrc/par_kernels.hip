@@ -58,9 +58,9 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 // wavefront reserves its nodes with ONE atomic; then all 64 lanes walk the (entity, bin) pairs side by side, so the
 // list-head exchanges of a wavefront are in flight together instead of one after the other.
 template <int ENT>
-__global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin_args a) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int stride = gridDim.x * blockDim.x;
+__device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par_bin_args& a, int block, int n_blocks) {
+    const int tid = block * blockDim.x + threadIdx.x;
+    const int stride = n_blocks * blockDim.x;
     const int s = a.set, o = a.set ^ 1;
 
     // wipe what the previous frame touched in the other set
@@ -132,6 +132,11 @@ __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin
             }
         }
     }
+}
+
+template <int ENT>
+__global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin_args a) {
+    bin_insert_body<ENT>(g, a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bin_args a) {
@@ -567,7 +572,8 @@ __global__ __launch_bounds__(256) void bgline_kernel(par_grid_dev g, par_render_
 // Requires W % 8 == 0 and 16-byte aligned planes; otherwise fill_generic_kernel runs.
 // ------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t out_rgba, const uint8_t* bglit) {
+__device__ __forceinline__ void fill_body(const par_render_args& a, uint32_t out_rgba, const uint8_t* bglit, int block,
+                                          int n_blocks) {
     const int W = a.W;
     const int rows = a.row_end - a.row_begin;
     const int cpr = (W + 511) >> 9;  // 512-pixel chunks per row
@@ -576,8 +582,8 @@ __global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t o
     const int wpb = blockDim.x >> 6;
     uint32_t* fb = reinterpret_cast<uint32_t*>(a.out.fb);
     // one chunk per wavefront per iteration; the chunk index is wave-uniform (kept in scalar registers)
-    for (int c = __builtin_amdgcn_readfirstlane((int)blockIdx.x * wpb + ((int)threadIdx.x >> 6)); c < n_chunks;
-         c += (int)gridDim.x * wpb) {
+    for (int c = __builtin_amdgcn_readfirstlane(block * wpb + ((int)threadIdx.x >> 6)); c < n_chunks;
+         c += n_blocks * wpb) {
         const int y = c / cpr, x0 = (c - y * cpr) << 9;
         const size_t rowbase = (size_t)y * W;
         if (fb) {
@@ -597,6 +603,22 @@ __global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t o
             const int x = x0 + lane * 8;
             if (x < W) *reinterpret_cast<uint2*>(a.out.lit + rowbase + x) = *reinterpret_cast<const uint2*>(bglit + x);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t out_rgba, const uint8_t* bglit) {
+    fill_body(a, out_rgba, bglit, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The background fill and the hash insert depend on nothing earlier in the frame and not on each other: one launch
+// for both (the first `n_insert` workgroups insert, the others fill) saves a link of the frame's launch chain.
+template <int ENT>
+__global__ __launch_bounds__(256) void insert_fill_kernel(par_grid_dev g, par_bin_args b, par_render_args a,
+                                                           uint32_t out_rgba, int n_insert) {
+    if ((int)blockIdx.x < n_insert) {
+        bin_insert_body<ENT>(g, b, (int)blockIdx.x, n_insert);
+    } else {
+        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_insert, (int)gridDim.x - n_insert);
     }
 }
 
@@ -1305,6 +1327,40 @@ hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, h
         hipLaunchKernelGGL(bin_insert_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
     } else {
         hipLaunchKernelGGL(bin_insert_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    }
+    return hipGetLastError();
+}
+
+// Insert + fill in one launch when the fill needs only the streaming kernel (frame and palette-index planes, aligned,
+// no lit plane). Returns hipErrorNotSupported (nothing launched) otherwise: the caller then launches them apart.
+hipError_t par_launch_insert_fill(const par_grid_dev& g, const par_bin_args& b, const par_render_args& a,
+                                  hipStream_t stream) {
+    const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
+    const bool pal_fast = !a.out.palidx || ((a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0));
+    if (a.dense || a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) {
+        return hipErrorNotSupported;
+    }
+    // Measured (three frames in flight / one): merged 27.0 / 47.5 us at 2048^2 against 29.6 / 54.3 apart, but
+    // 53.3 / 85.7 us at 4096^2 against 51.7 / 91.7 apart: there the fill is long (14 us) and holds back the
+    // resolve kernel, which costs the frame stream more than the saved launch. Merge up to 8 Mpixel.
+    if ((int64_t)(a.row_end - a.row_begin) * a.W > (int64_t)8 << 20) return hipErrorNotSupported;
+    const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);  // Color{127,127,127,0} * ambient
+    const uint32_t out_rgba = ch | (ch << 8) | (ch << 16);
+    const bool small = b.n <= 16384;
+    int64_t work = (int64_t)b.n * (small ? 4 : 1);
+    if (work < 65536) work = 65536;
+    int64_t n_insert = (work + 255) / 256;
+    if (n_insert > 4096) n_insert = 4096;
+    const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
+    int64_t n_fill = (chunks + 3) / 4;
+    if (n_fill > 2048) n_fill = 2048;
+    if (n_fill < 1) n_fill = 1;
+    if (small) {
+        hipLaunchKernelGGL(insert_fill_kernel<16>, dim3((unsigned)(n_insert + n_fill)), dim3(256), 0, stream, g, b, a,
+                           out_rgba, (int)n_insert);
+    } else {
+        hipLaunchKernelGGL(insert_fill_kernel<64>, dim3((unsigned)(n_insert + n_fill)), dim3(256), 0, stream, g, b, a,
+                           out_rgba, (int)n_insert);
     }
     return hipGetLastError();
 }
