@@ -1,15 +1,17 @@
 // par_kernels.hip — hand-written HIP kernels for gfx950 (MI355X / CDNA4).
 //
-// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is six launches:
+// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is six launches
+// (five up to 8 Mpixel, where insert and fill share one: insert_fill_kernel):
 //   bin_insert_kernel   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and deterministic
 //   bin_resolve_kernel  }   (+ which screen columns show any primitive this frame)
-//   columns_kernel      per occupied column: its compact slot list, the bin walks of trace_hash_for_light
-//                       (alt:399-500; they depend on the start bin only) and its tiles onto the work lists
-//   fill_kernel         background pixels of tiles no primitive reaches (alt:281 -> alt:735): pure streaming
+//   columns_kernel      per occupied column: its compact slot list and the bin walks of trace_hash_for_light
+//                       (alt:399-500; they depend on the start bin only) -> one record per column
+//                       (+ bgline_kernel: the W distinct background shadow rays, when every ray is traced)
+//   fill_kernel         background for the whole row range (alt:281 -> alt:735): pure streaming
 //   render_fast_kernel  trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect alt:40-83,
 //                       Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column records
-//   render_tiles_kernel the same, self-contained (walks in-kernel): overflowed columns, and every tile when every
-//                       ray is traced as the reference does
+//   render_tiles_kernel the same, self-contained (walks in-kernel): the columns that overflow a record
+//                       (PAR_FORCE_GENERIC=1: every tile)
 //
 // Float discipline: compiled with -ffp-contract=off; divisions are hipcc's default correctly-rounded fp32
 // division; min/max are the ?: forms of std::min/std::max so NaN handling follows the reference (first argument
