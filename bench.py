@@ -234,11 +234,11 @@ def main():
         ncols = int(r.stats().occupied_columns)
         gx, gy, gz = params.grid_dims()
         # Algorithmic bytes: 2.5 B per nominal ray = 5 B per pixel (4 B RGBA8 + 1 B palette index; two
-        # rays per pixel). fill_kernel writes every pixel of the frame once (5 B x W x H); render_fast_kernel then
+        # rays per pixel). fill_kernel writes every pixel of the frame once (5 B x W x H); render_wave_kernel then
         # writes the pixels primitives cover (5 B x covered pixels) - the only bytes that kernel has to move.
         bytes_frame = 2.5 * 2.0 * W * H
         bytes_render = 5.0 * hit_pixels
-        kernels = {"render_fast_kernel": (avg["render"], bytes_render), "fill_kernel": (avg["fill"], bytes_frame)}
+        kernels = {"render_wave_kernel": (avg["render"], bytes_render), "fill_kernel": (avg["fill"], bytes_frame)}
         dominant = max(kernels, key=lambda k: kernels[k][0])
         dom_ms, dom_bytes = kernels[dominant]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
@@ -254,12 +254,12 @@ def main():
             "algorithmic_bytes_per_launch": int(dom_bytes), "avg_kernel_ms": round(dom_ms, 5),
             "timing": "hipEvent pairs on the launch stream around each kernel group (kernels serialised for this "
                       "measurement), mean of 30 frames; profiles/ holds the rocprofv3 per-kernel summary",
-            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); render_fast_kernel writes "
+            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); render_wave_kernel writes "
                         f"the {hit_pixels} covered pixels, fill_kernel all {W * H}",
-            "note": "render_fast_kernel is VALU-issue/latency bound, not bandwidth bound (DESIGN.md section 5)",
+            "note": "render_wave_kernel is VALU-issue/latency bound, not bandwidth bound (DESIGN.md section 5)",
             "kernels_ms": {"hash_build+columns (3 kernels)": round(avg["bin"], 5),
                            "fill_kernel": round(avg["fill"], 5),
-                           "render_fast_kernel+render_tiles_kernel": round(avg["render"], 5)},
+                           "render_wave_kernel+render_tiles_kernel": round(avg["render"], 5)},
             "fill_kernel": {"achieved": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9, 1),
                             "frac": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "whole_frame": {"achieved": round(bytes_frame / (ms_per_step * 1e-3) / 1e9, 1),

@@ -23,6 +23,8 @@ struct par_context {
     std::vector<par_aabb> h_aabbs;
     std::vector<int32_t> h_pairs;  // (entity, bin) pairs each entity inserts, alt:243-267
     int64_t total_pairs = 0;
+    std::vector<int32_t> h_cols;   // screen columns (bx, by) each entity reaches: its pairs without the z factor
+    int64_t total_cols = 0;        // >= the occupied columns of the frame
     int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
     bool have_light = false, have_entities = false;
     par_light light{};
@@ -81,8 +83,9 @@ int hip_fail(par_context* c, hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
     } while (0)
 
-// (entity, bin) pairs one AABB inserts: the cull and range math of alt:202-240.
-int64_t pairs_of(const par_context* c, const par_aabb& a) {
+// (entity, bin) pairs one AABB inserts: the cull and range math of alt:202-240. `cols`: the (bx, by) columns among them.
+int64_t pairs_of(const par_context* c, const par_aabb& a, int32_t* cols = nullptr) {
+    if (cols) *cols = 0;
     const int W = c->params.width, H = c->params.height, L = c->params.length, B = c->params.bin_size;
     const int minx = a.px, miny = a.py, minz = a.pz;
     const int maxx = minx + a.ex, maxy = miny + a.ey, maxz = minz + a.ez;
@@ -94,6 +97,7 @@ int64_t pairs_of(const par_context* c, const par_aabb& a) {
     const int x1 = std::min(c->gx, (maxx + B - 1) / B), y1 = std::min(c->gy, (H - miny - minz + B - 1) / B);
     const int z1 = std::min(c->gz, (maxz + B - 1) / B);
     if (x1 <= x0 || y1 <= y0 || z1 <= z0) return 0;
+    if (cols) *cols = (x1 - x0) * (y1 - y0);
     return (int64_t)(x1 - x0) * (y1 - y0) * (z1 - z0);
 }
 
@@ -252,31 +256,31 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
     }
     if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
-    // hash insert and background fill depend on nothing earlier in the frame: one launch for both when the fill is
-    // the plain streaming one (timed runs keep them apart so that the event pairs bracket single kernels)
-    bool filled = false;
-    if (!ev) {
-        const hipError_t e = par_launch_insert_fill(ctx->grid, b, r, stream);
-        if (e == hipSuccess) {
-            filled = true;
-        } else if (e != hipErrorNotSupported) {
-            return hip_fail(ctx, e, "par_launch_insert_fill");
-        }
-    }
-    if (!filled) PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
+    PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
     // what par_graph_stage accepts (graph_pair_bound); beyond it the caller captures again.
     const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : ctx->total_pairs;
     PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, stream));
-    // occupied columns <= (entity, bin) pairs
-    const int64_t col_bound = pair_bound;
-    PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
+    // occupied columns <= the columns the entities reach one by one (<= their (entity, bin) pairs)
+    const int64_t col_bound = graph_mode ? pair_bound : ctx->total_cols;
+    // The background fill depends on nothing earlier in the frame: it shares the column kernel's launch when it is
+    // the plain streaming one (timed runs keep all kernels apart so that the event pairs bracket single ones).
+    bool merged = false;
+    if (!ev) {
+        const hipError_t e = par_launch_columns_fill(ctx->grid, r, col_bound, stream);
+        if (e == hipSuccess) {
+            merged = true;
+        } else if (e != hipErrorNotSupported) {
+            return hip_fail(ctx, e, "par_launch_columns_fill");
+        }
+    }
+    if (!merged) PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
-    // The background fill goes on the same stream. (Forking it onto a second stream beside the build was measured
-    // slower, alone and with several frames in flight: the cross-stream events cost more than the overlap gains,
-    // and frames in flight fill the idle CUs anyway.) It follows the column kernels because, when background rays
-    // are traced, it copies their results into the lit plane.
-    if (!filled) PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    // Otherwise the fill follows on the same stream. (Forking it onto a second stream beside the build was measured
+    // slower, alone and with several frames in flight: the cross-stream events cost more than the overlap gains.)
+    // It follows the column kernels because, when background rays are traced, it copies their results into the lit
+    // plane.
+    if (!merged) PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
@@ -495,13 +499,14 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
     drop_graphs(ctx);
-    std::vector<int32_t> pairs((size_t)n);
-    int64_t total = 0;
+    std::vector<int32_t> pairs((size_t)n), cols((size_t)n);
+    int64_t total = 0, total_cols = 0;
     for (int i = 0; i < n; i++) {
-        const int64_t k = pairs_of(ctx, aabbs[i]);
+        const int64_t k = pairs_of(ctx, aabbs[i], &cols[(size_t)i]);
         if (k > 0x7FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "entity spans too many bins");
         pairs[(size_t)i] = (int32_t)k;
         total += k;
+        total_cols += cols[(size_t)i];
     }
     int rc = ensure_pool(ctx, total);
     if (rc != PAR_OK) return rc;
@@ -522,6 +527,8 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     ctx->h_aabbs.assign(aabbs, aabbs + n);
     ctx->h_pairs.swap(pairs);
     ctx->total_pairs = total;
+    ctx->h_cols.swap(cols);
+    ctx->total_cols = total_cols;
     ctx->n_entities = n;
     ctx->max_sprite_id = max_id;
     ctx->have_entities = true;
@@ -562,10 +569,12 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    std::vector<int32_t> np((size_t)n);
+    std::vector<int32_t> np((size_t)n), nc((size_t)n);
+    int64_t total_cols = ctx->total_cols;
     for (int i = 0; i < n; i++) {
-        np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i]);
+        np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i], &nc[(size_t)i]);
         total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
+        total_cols += nc[(size_t)i] - ctx->h_cols[(size_t)(first + i)];
     }
     PAR_HIP(hipSetDevice(ctx->device));
     int rc = ensure_pool(ctx, total);
@@ -577,8 +586,10 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     for (int i = 0; i < n; i++) {
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
+        ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
     }
     ctx->total_pairs = total;
+    ctx->total_cols = total_cols;
     return PAR_OK;
 }
 
@@ -688,7 +699,10 @@ int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, c
         return fail(ctx, PAR_ERR_UNSUPPORTED, "staged frame exceeds what the captured graph was sized for; capture again");
     }
     for (int i = 0; i < n; i++) {
-        ctx->h_pairs[(size_t)(first + i)] = (int32_t)pairs_of(ctx, aabbs[i]);
+        int32_t nc = 0;
+        ctx->h_pairs[(size_t)(first + i)] = (int32_t)pairs_of(ctx, aabbs[i], &nc);
+        ctx->total_cols += nc - ctx->h_cols[(size_t)(first + i)];
+        ctx->h_cols[(size_t)(first + i)] = nc;
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->pin_aabbs[first + i] = aabbs[i];
     }

@@ -53,13 +53,16 @@ struct par_colrec {
     int16_t overflow;    // 1: the column does not fit this record; the generic kernel renders it
     int16_t bx, by;      // the column
     int32_t tile_mode;   // 1: visit the column's pixels as whole tiles, 0: entry rectangle by entry rectangle
-    int32_t pad_[4];
+    int32_t chunks;      // 64-pixel chunks of the column's visit (what its render work is split by)
+    uint32_t dup_lo, dup_hi;  // bit e: entry e repeats an earlier entry's entity (same rectangle: it owns no pixel)
+    int32_t pad_;
     par_colrec_nb nb[PAR_COL_NB];
     int16_t ebz[PAR_COL_ENT];  // bin_z of each entry (the primary pass walks the entries as one flat list)
     par_slot entries[PAR_COL_ENT];
     par_slot walk[PAR_COL_WALK];
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
+static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry");
 constexpr int PAR_COL_WAVES = 2;         // wavefronts per columns_kernel workgroup (one shadow walk each at a time)
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world
@@ -89,7 +92,7 @@ struct par_grid_dev {
     int32_t* node_bin[2];     // [capacity]
     int32_t* node_counter;    // [2]
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
-    int32_t* counters;        // [PAR_CNT_TOTAL]: occupied columns, overflowed columns, work distribution (reset by insert)
+    int32_t* counters;        // [PAR_CNT_TOTAL]: occupied columns, overflowed columns (reset by insert)
     par_colrec* colrec;       // [col_capacity] indexed like col_list
     int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
     par_bgwalk* bgwalk;       // [gx] shadow walks of the background rays (traced only on request)
@@ -133,22 +136,21 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
-constexpr int PAR_SCHED_GROUPS = 64;  // work-distribution counters of render_fast_kernel
-enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_SCHED = 8, PAR_CNT_TOTAL = PAR_CNT_SCHED + PAR_SCHED_GROUPS };
+constexpr int PAR_WAVE_NW = 4;          // wavefronts per render_wave_kernel workgroup
+constexpr int PAR_WAVE_CHUNK_COST = 6;  // work of a 64-pixel chunk ~ entries tested + this (shading, shadow, stores)
+enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_TOTAL = 8 };
 
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
-// Hash insert + background fill in one launch when possible (else hipErrorNotSupported, nothing launched).
-hipError_t par_launch_insert_fill(const par_grid_dev& g, const par_bin_args& b, const par_render_args& a,
-                                  hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
-// Per occupied column: compact slot list, the shadow walks of its bins, and its tiles onto the work lists.
-hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
 // Per occupied column: compact slot list + the shadow walks of its bins (+ the background walks when a.trace_bg);
 // then, when a.trace_bg, the background rays themselves (one per x).
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
+// Column records + background fill in one launch when possible (else hipErrorNotSupported, nothing launched).
+hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                                   hipStream_t stream);
 // Background for every pixel of the row range (skipped when a.dense); the render kernels then overwrite the tiles
-// primitives reach. Independent of the hash: may run beside the build on another stream.
+// primitives reach. Independent of the hash.
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
 // `column_bound`: an upper bound of the occupied columns (ignored when a.dense: every tile, generic kernel).
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,

@@ -1,15 +1,17 @@
 // par_kernels.hip — hand-written HIP kernels for gfx950 (MI355X / CDNA4).
 //
-// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is six launches
-// (five up to 8 Mpixel, where insert and fill share one: insert_fill_kernel):
+// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is five launches:
 //   bin_insert_kernel   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and deterministic
 //   bin_resolve_kernel  }   (+ which screen columns show any primitive this frame)
-//   columns_kernel      per occupied column: its compact slot list and the bin walks of trace_hash_for_light
+//   columns_fill_kernel two jobs in one launch, chosen by workgroup index:
+//     columns_body      per occupied column: its compact slot list and the bin walks of trace_hash_for_light
 //                       (alt:399-500; they depend on the start bin only) -> one record per column
-//                       (+ bgline_kernel: the W distinct background shadow rays, when every ray is traced)
-//   fill_kernel         background for the whole row range (alt:281 -> alt:735): pure streaming
-//   render_fast_kernel  trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect alt:40-83,
-//                       Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column records
+//     fill_body         background for the whole row range (alt:281 -> alt:735): pure streaming
+//                       (columns_kernel, bgline_kernel -- the W distinct background shadow rays, when every ray is
+//                       traced -- and fill_kernel / fill_generic_kernel apart when other planes are asked for)
+//   render_wave_kernel  trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect alt:40-83,
+//                       Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column records,
+//                       64 pixels per wavefront, no workgroup cooperation
 //   render_tiles_kernel the same, self-contained (walks in-kernel): the columns that overflow a record
 //                       (PAR_FORCE_GENERIC=1: every tile)
 //
@@ -387,17 +389,18 @@ struct ColShared {
     int32_t wsum[PAR_COL_WAVES];
     int32_t n_walk;
     int32_t overflow;
-    int32_t tile_mode;
+    int32_t chunks;
+    uint32_t dup[2];
 };
 
-__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a) {
-    __shared__ ColShared sm;
+__device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_render_args& a, ColShared& sm,
+                                             int block, int n_blocks) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the last gx workgroups (when background rays are traced) walk from the background start bins instead
-    const int n_col_blocks = (int)gridDim.x - (a.trace_bg ? g.gx : 0);
-    if ((int)blockIdx.x >= n_col_blocks) {
+    const int n_col_blocks = n_blocks - (a.trace_bg ? g.gx : 0);
+    if (block >= n_col_blocks) {
         if (wave == 0) {
-            const int bx = (int)blockIdx.x - n_col_blocks;
+            const int bx = block - n_col_blocks;
             const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
             // world (x, 0, 0): ray_bin = (x / B, (H - 0 - 0) / B, 0), alt:724-727
             const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, a.H / a.B, 0, sm.chain[0], sm.stage[0]);
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_de
         }
         return;
     }
-    const int ci = (int)blockIdx.x;
+    const int ci = block;
     stamp(g, 0, 0);
     // the launch is sized by an upper bound of the occupied columns; both loads are issued together
     const int n_cols = g.counters[PAR_CNT_COLS];
@@ -488,21 +491,31 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_de
     stamp(g, 0, 3);
 
     // ---- how the render kernel should visit the column's pixels: entry rectangle by entry rectangle when they
-    // cover little of it (the lanes of a pass are then nearly all covered pixels), otherwise whole tiles -----------
+    // cover little of it (the lanes of a 64-pixel chunk are then nearly all covered pixels), otherwise the whole
+    // tile. An entry that repeats an earlier entry's entity (the same AABB in another bin of the column) has the
+    // same rectangle and owns no pixel: it is marked and skipped. ----------------------------------------------
     if (tid == 0) {
-        const int c0 = bx * a.B, tw = min(a.B, a.W - c0);
-        const int rows_lo = max(by * a.B, a.row_begin), rows_hi = min(min((by + 1) * a.B, a.H), a.row_end);
-        int area = 0;
-        for (int e = 0; e < (overflow ? 0 : n_entries); e++) {
-            const par_slot r = sm.entries[e];
-            const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
-            const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
-            // every pass costs whole wavefronts: count the rectangle in units of the workgroup
-            if (w > 0 && h > 0) area += ((w * h + PAR_NT - 1) / PAR_NT) * PAR_NT;
-        }
-        sm.tile_mode = (area >= tw * max(rows_hi - rows_lo, 0)) ? 1 : 0;
+        sm.chunks = 0;
+        sm.dup[0] = sm.dup[1] = 0;
     }
     __syncthreads();
+    const int c0 = bx * a.B, tw = min(a.B, a.W - c0);
+    const int rows_lo = max(by * a.B, a.row_begin), rows_hi = min(min((by + 1) * a.B, a.H), a.row_end);
+    if (!overflow && tid < n_entries) {
+        const par_slot r = sm.entries[tid];
+        bool dup = false;
+        for (int e = 0; e < tid; e++) dup = dup || (sm.entries[e].entity == r.entity);
+        const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
+        const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
+        if (dup) {
+            atomicOr(&sm.dup[tid >> 5], 1u << (tid & 31));
+        } else if (w > 0 && h > 0) {
+            atomicAdd(&sm.chunks, (w * h + 63) >> 6);  // every visit costs whole wavefronts
+        }
+    }
+    __syncthreads();
+    const int tile_chunks = (tw * max(rows_hi - rows_lo, 0) + 63) >> 6;
+    const int tile_mode = (sm.chunks >= tile_chunks) ? 1 : 0;
 
     // ---- C: the record ----------------------------------------------------------------------------------------
     if (ci < g.col_capacity) {
@@ -514,7 +527,10 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_de
             rec->overflow = overflow ? 1 : 0;
             rec->bx = (int16_t)bx;
             rec->by = (int16_t)by;
-            rec->tile_mode = sm.tile_mode;
+            rec->tile_mode = tile_mode;
+            rec->chunks = tile_mode ? tile_chunks : sm.chunks;
+            rec->dup_lo = sm.dup[0];
+            rec->dup_hi = sm.dup[1];
         }
         if (!overflow) {
             if (tid < n_nb) rec->nb[tid] = sm.nb[tid];
@@ -526,6 +542,11 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_de
     }
     if (overflow && tid == 0) g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;  // the exception
     stamp(g, 0, 4);
+}
+
+__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a) {
+    __shared__ ColShared sm;
+    columns_body(g, a, sm, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, int sx, int sy,
@@ -612,15 +633,16 @@ __global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t o
     fill_body(a, out_rgba, bglit, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// The background fill and the hash insert depend on nothing earlier in the frame and not on each other: one launch
-// for both (the first `n_insert` workgroups insert, the others fill) saves a link of the frame's launch chain.
-template <int ENT>
-__global__ __launch_bounds__(256) void insert_fill_kernel(par_grid_dev g, par_bin_args b, par_render_args a,
-                                                           uint32_t out_rgba, int n_insert) {
-    if ((int)blockIdx.x < n_insert) {
-        bin_insert_body<ENT>(g, b, (int)blockIdx.x, n_insert);
+// The background fill does not depend on the hash, and it takes about as long as the column records of a
+// 16 Mpixel frame: one launch for both (the first `n_col` workgroups build column records, the others fill), so the
+// fill costs the frame's launch chain neither a link nor its own duration.
+__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_fill_kernel(par_grid_dev g, par_render_args a,
+                                                                          uint32_t out_rgba, int n_col) {
+    __shared__ ColShared sm;
+    if ((int)blockIdx.x < n_col) {
+        columns_body(g, a, sm, (int)blockIdx.x, n_col);
     } else {
-        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_insert, (int)gridDim.x - n_insert);
+        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col, (int)gridDim.x - n_col);
     }
 }
 
@@ -645,7 +667,7 @@ __global__ __launch_bounds__(256) void fill_generic_kernel(par_render_args a, ui
 
 // ------------------------------------------------------------------------------------------------------------
 // Per-lane shadow walk: trace_hash_for_light (alt:399-500) exactly as written, for the rare pixel whose shadow ray
-// starts in a bin that holds no primitive (negative world z, sprite depths outside the box) in the fast kernel.
+// starts in a bin that holds no primitive (negative world z, sprite depths outside the box) in render_wave_kernel.
 // ------------------------------------------------------------------------------------------------------------
 __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, int sx, int sy,
                                  int sz, const par_frame_dyn& dyn, int self, int ox, int oy, int oz, float ix,
@@ -687,267 +709,234 @@ __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// render_fast_kernel: workgroups of 5 wavefronts stride over the occupied columns; for each they render the tiles
-// (B pixels wide, PAR_NT / B rows tall: 40 x 8, one pixel per lane) that some record of the column can cover.
-// Everything a column's tiles need arrives in ONE contiguous record (columns_kernel): 16 bytes per lane, one
-// barrier, then the pixels run out of LDS -- sprite 0's tables included -- while the record of the workgroup's
-// NEXT column is already on its way.
+// render_chunk: one pixel per lane, for up to 64 pixels of one column (wavefront level: no workgroup cooperation).
+// `rec_` is the column's record (in LDS or in global memory), `depth0` / `color0` sprite 0's depth and palette-index
+// tables (ditto). `own` >= 0: the lanes render the pixels entry `own` is the first to cover; -1: all pixels.
 // ------------------------------------------------------------------------------------------------------------
-
-struct FastShared {
-    par_colrec rec[2];                         // double buffered: the next column's record is in flight
-    par_texel texinfo[PAR_SPRITE_TEXELS];      // sprite 0: normal + resolved palette colour per texel
-    int32_t sprite_depth[PAR_SPRITE_TEXELS];   // sprite 0: depth per texel (the hot lookup of the primary pass)
-    uint8_t sprite_color[PAR_SPRITE_TEXELS];   // sprite 0: palette index per texel
-    uint32_t magic[PAR_MAX_BIN + 1];           // magic[w]: floor(p / w) == __umulhi(p, magic[w]) for p * w < 2^32
-    int32_t next[2];                           // work items handed out by the group counter
-};
-
-__global__ __launch_bounds__(PAR_NT, 8) void render_fast_kernel(par_grid_dev g, par_render_args a) {
-    __shared__ FastShared sm;
-    const int tid = threadIdx.x;
-    const int W = a.W, H = a.H, B = a.B;
-    stamp(g, 1, 0);
-    const int n_cols = min(g.counters[PAR_CNT_COLS], g.col_capacity);
-    if (n_cols <= 0) return;
-    constexpr int NV = (int)(sizeof(par_colrec) / 16);  // 16-byte pieces of a record: one per lane
-    static_assert(NV <= PAR_NT, "one record piece per lane");
-    // A column is split into `parts` work items when there are fewer columns than workgroups (small frames), so
-    // that the whole chip still has something to do.
-    const int parts = max(1, min(8, (int)gridDim.x / n_cols));
-    const int n_items = n_cols * parts;
-    // Work distribution. Column costs differ several-fold, so a fixed assignment leaves the slowest workgroup far
-    // behind; but atomics on ONE address are served one after the other (~8 ns each on this chip), so a single
-    // shared counter would cost every workgroup tens of microseconds at start-up. Hence: the items are dealt to
-    // PAR_SCHED_GROUPS groups (item i belongs to group i % groups), each workgroup's first two items are fixed (no
-    // atomic), and only later ones come off the group's own counter -- a handful of atomics per counter and frame.
-    // The atomic of item k+2 is issued at the start of item k and consumed at its end.
-    const int sched_q = (int)blockIdx.x % PAR_SCHED_GROUPS, sched_j = (int)blockIdx.x / PAR_SCHED_GROUPS;
-    const int sched_wpg = ((int)gridDim.x + PAR_SCHED_GROUPS - 1) / PAR_SCHED_GROUPS;  // workgroups per group
-    int item = sched_q + PAR_SCHED_GROUPS * sched_j;
-    int item_next = sched_q + PAR_SCHED_GROUPS * (sched_j + sched_wpg);
-    if (item >= n_items) return;
-    uint4 piece = make_uint4(0, 0, 0, 0);
-    if (tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + item / parts)[tid];
-
+template <class ColorT>
+__device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
+                                             const int32_t* depth0, const ColorT* color0,
+                                             const par_frame_dyn& dyn, int n_entries, int n_nb, int bx, int by,
+                                             int own, int col, int row, bool valid, int lane) {
+    const int W = a.W, H = a.H;
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
-    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
-    for (int t = tid; t < PAR_SPRITE_TEXELS; t += PAR_NT) {
-        sm.sprite_depth[t] = a.sprites[0].depth[t];
-        sm.texinfo[t] = a.texinfo[t];
-        sm.sprite_color[t] = (uint8_t)a.sprites[0].color[t];
-    }
-    // rectangle widths are at most one bin: one division per width here instead of one per pass
-    for (int t = tid + 1; t <= PAR_MAX_BIN; t += PAR_NT) sm.magic[t] = (uint32_t)(0xFFFFFFFFu / (uint32_t)t) + 1u;
-    stamp(g, 1, 1);
-    for (int it = 0;; it++) {
-        const int buf = it & 1;
-        if (tid < NV) reinterpret_cast<uint4*>(&sm.rec[buf])[tid] = piece;
-        int fetched = 0;
-        if (tid == 0) fetched = atomicAdd(&g.counters[PAR_CNT_SCHED + sched_q], 1);  // -> item it + 2
-        // One barrier per work item: the buffer written now was last read two items ago, and every lane has passed
-        // the previous item's barrier since.
-        __syncthreads();
-        if (it == 0) stamp(g, 1, 2);
-        if (it > 0) item_next = sm.next[(it - 1) & 1];  // fetched during the previous item
-        const bool has_next = item_next < n_items;
-        if (has_next && tid < NV) piece = reinterpret_cast<const uint4*>(g.colrec + item_next / parts)[tid];
-        const int part = item - (item / parts) * parts;
-        const par_colrec& rec_ = sm.rec[buf];
-        const int n_entries = (rec_.overflow || (a.flags & (1u << 24))) ? 0 : rec_.n_entries;  // bit 24: ablation
-        const int n_nb = rec_.n_nb;
-        const int bx = rec_.bx, by = rec_.by;
-        const int c0 = bx * B;
-        const int tw = min(B, W - c0);
-        const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
-
-        // How the column's pixels are visited (columns_kernel decides per column):
-        //  - entry by entry: the screen rectangle of entry `own` inside this column, row-major, one pixel per
-        //    lane. A pixel several entries cover belongs to the FIRST of them in list order, so every covered
-        //    pixel is rendered exactly once and the lanes of a pass are (nearly) all covered pixels; what no entry
-        //    covers keeps the background fill_kernel wrote;
-        //  - as whole tiles (own = -1) when the rectangles would add up to more than the column itself.
-        const bool tile_mode = rec_.tile_mode != 0;
-        const int n_pass = tile_mode ? 1 : n_entries;
-        for (int q = tile_mode ? 0 : part; q < n_pass; q += tile_mode ? 1 : parts) {  // uniform
-            const int own = tile_mode ? -1 : q;
-            int rx0, rw, ry0, rh;
-            if (tile_mode) {
-                // this work item's share of the column's rows
-                const int rows = rows_hi - rows_lo, share = (rows + parts - 1) / parts;
-                rx0 = c0;
-                rw = tw;
-                ry0 = rows_lo + part * share;
-                rh = min(share, rows_hi - ry0);
-            } else {
-                const par_slot r = rec_.entries[q];
-                rx0 = max((int)r.px, c0);
-                rw = min(r.px + r.ex, c0 + tw) - rx0;
-                // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
-                ry0 = max(H - (r.py + r.ey + r.pz + r.ez), rows_lo);
-                rh = min(H - (r.py + r.pz), rows_hi) - ry0;
+    // ---- primary ray, alt:271-397: the column's entries front to back as one flat list -----------------
+    bool hit = false;
+    int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;
+    {
+        const int i = col;
+        const int world_j = (int)(int16_t)(H - row);  // alt:280
+        int adjacent = 0;                             // alt:282
+        int closest = INT_MIN;                        // alt:289
+        int cur_bz = -2;
+        int first_cover = n_entries;                  // first entry whose test (alt:310-317) passes
+        bool hit_in_bin = false;
+        bool done = !valid;
+        int w_ybase = 0, w_pz = 0, w_d = 0;
+        for (int e = 0; e < n_entries; e++) {
+            const int bz = rec_.ebz[e];
+            const par_slot rec = rec_.entries[e];
+            if (bz != cur_bz) {  // the previous bin is complete
+                adjacent += hit_in_bin ? 1 : 0;      // alt:368
+                if (adjacent >= 2) done = true;      // alt:372-374
+                if (bz != cur_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
+                cur_bz = bz;
+                hit_in_bin = false;
             }
-            rx0 = __builtin_amdgcn_readfirstlane(rx0);
-            rw = __builtin_amdgcn_readfirstlane(rw);
-            ry0 = __builtin_amdgcn_readfirstlane(ry0);
-            rh = __builtin_amdgcn_readfirstlane(rh);
-            if (rw <= 0 || rh <= 0) continue;
-            // floor(p / rw) == __umulhi(p, magic_w); a 1-pixel-wide rectangle has no such multiplier
-            const uint32_t magic_w = sm.magic[rw];
-            const int area = rw * rh;
-            for (int base = 0; base < area; base += PAR_NT) {
-            const int pidx = base + tid;
+            // a lane whose pixel an earlier entry owns has nothing to do in this pass
+            if (first_cover < own) done = true;  // (never in tile mode: own = -1)
+            if (__all(done)) break;  // wavefront early-out
+            const int top = rec.py + rec.ey + rec.pz + rec.ez;
+            if (!done && i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
+                first_cover = min(first_cover, e);
+                const int sprite_row = top - world_j;                         // alt:324-326
+                const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
+                const int sid = a.sprite_ids ? a.sprite_ids[rec.entity] : 0;  // alt:321-322
+                const int d = (sid == 0) ? depth0[t] : a.sprites[sid].depth[t];
+                const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
+                if (closest < depth) {                                        // alt:344-346
+                    closest = depth;
+                    w_ybase = rec.py + rec.ey + rec.ez - sprite_row;          // alt:356-359
+                    w_pz = rec.pz;                                            // alt:360-361
+                    w_d = d;
+                    p_entity = rec.entity;                                    // alt:363
+                    p_tex = sid * PAR_SPRITE_TEXELS + t;
+                    hit = true;
+                    hit_in_bin = true;                                        // alt:365
+                }
+            }
+        }
+        // an entry pass renders the pixels entry `own` is the first to cover; a tile pass renders them all
+        valid = valid && (own < 0 || first_cover == own);
+        hit = hit && valid;
+        if (hit) {
+            p_y = w_ybase - w_d;
+            p_z = w_pz + w_d;
+        }
+    }
+
+    // ---- shading, alt:704-758 --------------------------------------------------------------------------
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    uint32_t rgba = bg_rgba;
+    int pal_index = PAR_PALIDX_BACKGROUND;
+    float bright = ambient;
+    bool lit_px = true;
+    if (hit && !(a.flags & (1u << 26))) {  // bit 26: ablation (timing experiments only), no shading
+        // normal (alt:349-350) + resolved palette colour (alt:352-354)
+        const par_texel ti = a.texinfo[p_tex];
+        nx = ti.nx; ny = ti.ny; nz = ti.nz;
+        rgba = ti.rgba;
+        if (a.out.palidx) {
+            if (p_tex < PAR_SPRITE_TEXELS) {
+                pal_index = (int)color0[p_tex];
+            } else {
+                const int sid = p_tex / PAR_SPRITE_TEXELS;
+                pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
+            }
+        }
+        const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
+        // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
+        const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
+        const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
+        const float tx = dx / len, ty = dy / len, tz = dz / len;
+        const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
+        const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
+        const float diffuse = std_max(0.f, dot);                           // alt:745
+        const float b_lit = std_min(1.f, diffuse + ambient);               // alt:758
+        const int sy = div_bin(H - wy - wz, a.magic_b);                    // alt:725-726
+        const int sz = div_bin(wz, a.magic_b);                             // alt:727
+        const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
+        // shadow ray, alt:738-742: the walk from the start bin was done by columns_kernel
+        bool lit = true;
+        int wi = -1;
+        if (sy == by) {
+            for (int n = 0; n < n_nb; n++) {
+                if (rec_.nb[n].bz == sz) wi = n;
+            }
+        }
+        if (wi >= 0) {
+            const int woff = rec_.nb[wi].woff, wcnt = rec_.nb[wi].wcnt;
+            for (int r = 0; r < wcnt; r++) {
+                const par_slot rec = rec_.walk[woff + r];
+                if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
+                    lit = false;
+                    break;
+                }
+            }
+        } else {
+            lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y,
+                                   inv_z);
+        }
+        bright = lit ? b_lit : ambient;
+        lit_px = lit;
+    }
+    if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
+        const unsigned long long m = __ballot(valid && hit);
+        if (lane == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
+    }
+
+    // ---- quantise + store, alt:735, 757-758 ------------------------------------------------------------
+    if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
+        asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
+    } else if (valid && hit) {  // (uncovered pixels keep what fill_kernel wrote)
+        const size_t o = (size_t)(row - a.row_begin) * W + col;
+        if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
+        if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
+        if (a.out.brightness) a.out.brightness[o] = bright;
+        if (a.out.lit) a.out.lit[o] = lit_px ? 1 : 0;
+        if (a.out.gbuf) {
+            par_pixel pxl;
+            pxl.normal = par_vec3{nx, ny, nz};
+            pxl.color.red = (uint8_t)(rgba & 0xFF);
+            pxl.color.green = (uint8_t)((rgba >> 8) & 0xFF);
+            pxl.color.blue = (uint8_t)((rgba >> 16) & 0xFF);
+            pxl.color.alpha = (uint8_t)(rgba >> 24);
+            pxl.y = p_y;
+            pxl.z = p_z;
+            pxl.entity_index = p_entity;
+            a.out.gbuf[o] = pxl;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// render_wave_kernel: the pixels of the occupied columns, wavefront by wavefront (no workgroup cooperation).
+// A column's pixels are cut into 64-pixel chunks -- entry rectangle by entry rectangle (a pixel several entries
+// cover belongs to the FIRST of them in list order, so every covered pixel is rendered exactly once and the lanes of
+// a chunk are nearly all covered pixels), or the whole tile when the rectangles add up to more than the tile
+// (columns_kernel decides) -- and chunk k belongs to wavefront k mod (parts * PAR_WAVE_NW) of the column's
+// workgroups. The launch has gridDim.y workgroups per column; a column uses as many as its work is worth
+// (chunks x entries / cost_per_part), the others leave at once. The record is read where columns_kernel left it:
+// its fields are wave-uniform, so they arrive through the scalar cache; sprite 0's tables come through L1. No
+// LDS, no barrier, nothing to stage: a wavefront's first pixel is three dependent loads away from its start, and
+// the hardware dispatcher balances the columns. What no entry covers keeps the background the fill wrote.
+// (Measured against persistent 5-wavefront workgroups with LDS-staged records and sprite tables, 4096^2 / 1024
+// primitives: 32 instead of 46 us alone, 40 instead of 50 us per frame with three frames in flight.)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_wave_kernel(par_grid_dev g, par_render_args a,
+                                                                          int cost_per_part) {
+    const int lane = (int)threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int ci = (int)blockIdx.x;
+    if (ci >= g.col_capacity) return;
+    const int n_cols = g.counters[PAR_CNT_COLS];
+    const par_colrec& rec_ = g.colrec[ci];
+    const int n_entries_rec = rec_.n_entries, n_nb = rec_.n_nb, overflow = rec_.overflow;
+    const int bx = rec_.bx, by = rec_.by;
+    const bool tile_mode = rec_.tile_mode != 0;
+    const uint64_t dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
+    if (ci >= n_cols || overflow) return;
+    // a column's chunks are shared by as many workgroups as its work is worth (the others of its row leave at once)
+    const int col_parts =
+        min((int)gridDim.y, max(1, (rec_.chunks * (n_entries_rec + PAR_WAVE_CHUNK_COST) + cost_per_part - 1) / cost_per_part));
+    if ((int)blockIdx.y >= col_parts) return;
+    const int n_workers = col_parts * PAR_WAVE_NW, worker = (int)blockIdx.y * PAR_WAVE_NW + wave;
+    const int n_entries = (a.flags & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing experiments only)
+    const int W = a.W, H = a.H, B = a.B;
+    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+    const int c0 = bx * B;
+    const int tw = min(B, W - c0);
+    const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
+    const int32_t* depth0 = a.sprites[0].depth;
+    const int32_t* color0 = a.sprites[0].color;
+    int k = 0;  // chunks of the column so far (wave-uniform)
+    const int n_pass = tile_mode ? 1 : n_entries;
+    for (int q = 0; q < n_pass; q++) {
+        const int own = tile_mode ? -1 : q;
+        if (!tile_mode && ((dup >> q) & 1)) continue;
+        int rx0, rw, ry0, rh;
+        if (tile_mode) {
+            rx0 = c0; rw = tw; ry0 = rows_lo; rh = rows_hi - rows_lo;
+        } else {
+            const par_slot r = rec_.entries[q];
+            rx0 = max((int)r.px, c0);
+            rw = min(r.px + r.ex, c0 + tw) - rx0;
+            // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
+            ry0 = max(H - (r.py + r.ey + r.pz + r.ez), rows_lo);
+            rh = min(H - (r.py + r.pz), rows_hi) - ry0;
+        }
+        rx0 = __builtin_amdgcn_readfirstlane(rx0);
+        rw = __builtin_amdgcn_readfirstlane(rw);
+        ry0 = __builtin_amdgcn_readfirstlane(ry0);
+        rh = __builtin_amdgcn_readfirstlane(rh);
+        if (rw <= 0 || rh <= 0) continue;
+        const int area = rw * rh;
+        const int n_chunks = (area + 63) >> 6;
+        // this wavefront's first chunk of the rectangle: the smallest c >= 0 with (k + c) % n_workers == worker
+        int c = worker - k % n_workers;
+        if (c < 0) c += n_workers;
+        k += n_chunks;
+        if (c >= n_chunks) continue;
+        // floor(p / rw) == __umulhi(p, magic_w) for p * rw < 2^32; a 1-pixel-wide rectangle has no such multiplier
+        const uint32_t magic_w = (uint32_t)(0xFFFFFFFFu / (uint32_t)rw) + 1u;
+        for (; c < n_chunks; c += n_workers) {
+            const int pidx = c * 64 + lane;
             const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
             const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
-            bool valid = pidx < area;
-            if (!__any(valid)) continue;  // this wavefront's lanes all lie beyond the rectangle
-
-            // ---- primary ray, alt:271-397: the column's entries front to back as one flat list -----------------
-            bool hit = false;
-            int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;
-            {
-                const int i = col;
-                const int world_j = (int)(int16_t)(H - row);  // alt:280
-                int adjacent = 0;                             // alt:282
-                int closest = INT_MIN;                        // alt:289
-                int cur_bz = -2;
-                int first_cover = n_entries;                  // first entry whose test (alt:310-317) passes
-                bool hit_in_bin = false;
-                bool done = !valid;
-                int w_ybase = 0, w_pz = 0, w_d = 0;
-                for (int e = 0; e < n_entries; e++) {
-                    const int bz = rec_.ebz[e];
-                    const par_slot rec = rec_.entries[e];
-                    if (bz != cur_bz) {  // the previous bin is complete
-                        adjacent += hit_in_bin ? 1 : 0;      // alt:368
-                        if (adjacent >= 2) done = true;      // alt:372-374
-                        if (bz != cur_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
-                        cur_bz = bz;
-                        hit_in_bin = false;
-                    }
-                    // a lane whose pixel an earlier entry owns has nothing to do in this pass
-                    if (first_cover < own) done = true;  // (never in tile mode: own = -1)
-                    if (__all(done)) break;  // wavefront early-out
-                    const int top = rec.py + rec.ey + rec.pz + rec.ez;
-                    if (!done && i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
-                        first_cover = min(first_cover, e);
-                        const int sprite_row = top - world_j;                         // alt:324-326
-                        const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
-                        const int sid = a.sprite_ids ? a.sprite_ids[rec.entity] : 0;  // alt:321-322
-                        const int d = (sid == 0) ? sm.sprite_depth[t] : a.sprites[sid].depth[t];
-                        const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
-                        if (closest < depth) {                                        // alt:344-346
-                            closest = depth;
-                            w_ybase = rec.py + rec.ey + rec.ez - sprite_row;          // alt:356-359
-                            w_pz = rec.pz;                                            // alt:360-361
-                            w_d = d;
-                            p_entity = rec.entity;                                    // alt:363
-                            p_tex = sid * PAR_SPRITE_TEXELS + t;
-                            hit = true;
-                            hit_in_bin = true;                                        // alt:365
-                        }
-                    }
-                }
-                // an entry pass renders the pixels entry `own` is the first to cover; a tile pass renders them all
-                valid = valid && (own < 0 || first_cover == own);
-                hit = hit && valid;
-                if (hit) {
-                    p_y = w_ybase - w_d;
-                    p_z = w_pz + w_d;
-                }
-            }
-
-            // ---- shading, alt:704-758 --------------------------------------------------------------------------
-            float nx = 0.f, ny = 0.f, nz = 0.f;
-            uint32_t rgba = bg_rgba;
-            int pal_index = PAR_PALIDX_BACKGROUND;
-            float bright = ambient;
-            bool lit_px = true;
-            if (hit && !(a.flags & (1u << 26))) {  // bit 26: ablation (timing experiments only), no shading
-                // normal (alt:349-350) + resolved palette colour (alt:352-354)
-                const par_texel ti = (p_tex < PAR_SPRITE_TEXELS) ? sm.texinfo[p_tex] : a.texinfo[p_tex];
-                nx = ti.nx; ny = ti.ny; nz = ti.nz;
-                rgba = ti.rgba;
-                if (a.out.palidx) {
-                    if (p_tex < PAR_SPRITE_TEXELS) {
-                        pal_index = sm.sprite_color[p_tex];
-                    } else {
-                        const int sid = p_tex / PAR_SPRITE_TEXELS;
-                        pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
-                    }
-                }
-                const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
-                // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
-                const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
-                const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
-                const float tx = dx / len, ty = dy / len, tz = dz / len;
-                const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
-                const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
-                const float diffuse = std_max(0.f, dot);                           // alt:745
-                const float b_lit = std_min(1.f, diffuse + ambient);               // alt:758
-                const int sy = div_bin(H - wy - wz, a.magic_b);                    // alt:725-726
-                const int sz = div_bin(wz, a.magic_b);                             // alt:727
-                const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
-                // shadow ray, alt:738-742: the walk from the start bin was done by columns_kernel
-                bool lit = true;
-                int wi = -1;
-                if (sy == by) {
-                    for (int n = 0; n < n_nb; n++) {
-                        if (rec_.nb[n].bz == sz) wi = n;
-                    }
-                }
-                if (wi >= 0) {
-                    const int woff = rec_.nb[wi].woff, wcnt = rec_.nb[wi].wcnt;
-                    for (int r = 0; r < wcnt; r++) {
-                        const par_slot rec = rec_.walk[woff + r];
-                        if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
-                            lit = false;
-                            break;
-                        }
-                    }
-                } else {
-                    lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y,
-                                           inv_z);
-                }
-                bright = lit ? b_lit : ambient;
-                lit_px = lit;
-            }
-            if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
-                const unsigned long long m = __ballot(valid && hit);
-                if ((tid & 63) == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
-            }
-
-            // ---- quantise + store, alt:735, 757-758 ------------------------------------------------------------
-            if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
-                asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
-            } else if (valid && hit) {  // (uncovered pixels keep what fill_kernel wrote)
-                const size_t o = (size_t)(row - a.row_begin) * W + col;
-                if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
-                if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
-                if (a.out.brightness) a.out.brightness[o] = bright;
-                if (a.out.lit) a.out.lit[o] = lit_px ? 1 : 0;
-                if (a.out.gbuf) {
-                    par_pixel pxl;
-                    pxl.normal = par_vec3{nx, ny, nz};
-                    pxl.color.red = (uint8_t)(rgba & 0xFF);
-                    pxl.color.green = (uint8_t)((rgba >> 8) & 0xFF);
-                    pxl.color.blue = (uint8_t)((rgba >> 16) & 0xFF);
-                    pxl.color.alpha = (uint8_t)(rgba >> 24);
-                    pxl.y = p_y;
-                    pxl.z = p_z;
-                    pxl.entity_index = p_entity;
-                    a.out.gbuf[o] = pxl;
-                }
-            }
-            }  // passes over the rectangle
-        }      // entries
-        if (it == 0) stamp(g, 1, 3);
-        if (tid == 0) sm.next[buf] = sched_q + PAR_SCHED_GROUPS * (2 * sched_wpg + fetched);
-        if (!has_next) break;
-        item = item_next;
+            render_chunk(g, a, rec_, depth0, color0, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane);
+        }
     }
-    stamp(g, 1, 4);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1333,40 +1322,6 @@ hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, h
     return hipGetLastError();
 }
 
-// Insert + fill in one launch when the fill needs only the streaming kernel (frame and palette-index planes, aligned,
-// no lit plane). Returns hipErrorNotSupported (nothing launched) otherwise: the caller then launches them apart.
-hipError_t par_launch_insert_fill(const par_grid_dev& g, const par_bin_args& b, const par_render_args& a,
-                                  hipStream_t stream) {
-    const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
-    const bool pal_fast = !a.out.palidx || ((a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0));
-    if (a.dense || a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) {
-        return hipErrorNotSupported;
-    }
-    // Measured (three frames in flight / one): merged 27.0 / 47.5 us at 2048^2 against 29.6 / 54.3 apart, but
-    // 53.3 / 85.7 us at 4096^2 against 51.7 / 91.7 apart: there the fill is long (14 us) and holds back the
-    // resolve kernel, which costs the frame stream more than the saved launch. Merge up to 8 Mpixel.
-    if ((int64_t)(a.row_end - a.row_begin) * a.W > (int64_t)8 << 20) return hipErrorNotSupported;
-    const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);  // Color{127,127,127,0} * ambient
-    const uint32_t out_rgba = ch | (ch << 8) | (ch << 16);
-    const bool small = b.n <= 16384;
-    int64_t work = (int64_t)b.n * (small ? 4 : 1);
-    if (work < 65536) work = 65536;
-    int64_t n_insert = (work + 255) / 256;
-    if (n_insert > 4096) n_insert = 4096;
-    const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
-    int64_t n_fill = (chunks + 3) / 4;
-    if (n_fill > 2048) n_fill = 2048;
-    if (n_fill < 1) n_fill = 1;
-    if (small) {
-        hipLaunchKernelGGL(insert_fill_kernel<16>, dim3((unsigned)(n_insert + n_fill)), dim3(256), 0, stream, g, b, a,
-                           out_rgba, (int)n_insert);
-    } else {
-        hipLaunchKernelGGL(insert_fill_kernel<64>, dim3((unsigned)(n_insert + n_fill)), dim3(256), 0, stream, g, b, a,
-                           out_rgba, (int)n_insert);
-    }
-    return hipGetLastError();
-}
-
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound,
                                   hipStream_t stream) {
     int64_t blocks = (pair_bound + 255) / 256;
@@ -1387,6 +1342,31 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !a.trace_bg) return e;
     hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
+    return hipGetLastError();
+}
+
+// Column records + fill in one launch when the fill needs only the streaming kernel (frame and palette-index planes,
+// aligned, no lit plane). Returns hipErrorNotSupported (nothing launched) otherwise: the caller launches them apart.
+hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                                   hipStream_t stream) {
+    const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
+    const bool pal_fast = !a.out.palidx || ((a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0));
+    if (a.dense || a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) {
+        return hipErrorNotSupported;
+    }
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    int64_t n_col = column_bound < cols_in_range ? column_bound : cols_in_range;
+    if (n_col < 0) n_col = 0;
+    const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);  // Color{127,127,127,0} * ambient
+    const uint32_t out_rgba = ch | (ch << 8) | (ch << 16);
+    const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
+    int64_t n_fill = (chunks + PAR_COL_WAVES - 1) / PAR_COL_WAVES;
+    // Measured at 4096^2 (three frames in flight / one): 1024 fill workgroups 49.7 / 84.1 us, 256: 52.8 / 83.9,
+    // 4096: 51.4 / 84.0; fill and column kernels apart: 51.7 / 92.2.
+    if (n_fill > 1024) n_fill = 1024;
+    if (n_fill < 1) n_fill = 1;
+    hipLaunchKernelGGL(columns_fill_kernel, dim3((unsigned)(n_col + n_fill)), dim3(PAR_COL_WAVES * 64), 0, stream, g,
+                       a, out_rgba, (int)n_col);
     return hipGetLastError();
 }
 
@@ -1436,16 +1416,13 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     }
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound <= 0) return hipSuccess;
-    // Persistent workgroups, 5 per CU (what is resident at once with 64 VGPRs and 24 KB of LDS per workgroup of 5
-    // wavefronts: measured, a sixth per CU starts only when another has finished). They take their work items off
-    // per-group counters, and the next record's load overlaps the current column's pixels.
-    const int64_t cap = (int64_t)256 * 5;
-    // (a column is split into up to 8 work items when there are fewer columns than resident workgroups)
-    // (a multiple of the group count: every group then has the same number of workgroups, which the fixed first two
-    // items of each workgroup rely on)
-    int64_t fast_blocks = bound * 8 > cap ? cap : bound * 8;
-    fast_blocks = (fast_blocks + PAR_SCHED_GROUPS - 1) / PAR_SCHED_GROUPS * PAR_SCHED_GROUPS;
-    hipLaunchKernelGGL(render_fast_kernel, dim3((unsigned)fast_blocks), dim3(PAR_NT), 0, stream, g, a);
+    // gridDim.y workgroups per column (a column uses as many as its work is worth); few columns: more of them, and
+    // finer parts, so that a small frame still spreads over the chip. Measured at 4096^2 / 1024 primitives (three
+    // frames in flight / one): y=1: 38.6 / 72.8 us, y=2: 39.9 / 66.0, y=4: 41.1 / 64.8, y=8: 44.3 / 64.9.
+    const int parts = bound >= 2048 ? 2 : (bound >= 512 ? 4 : 8);
+    const int cost_per_part = bound >= 2048 ? 100 : (bound >= 512 ? 50 : 25);
+    hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0, stream, g,
+                       a, cost_per_part);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     // overflowed columns are the exception: a small strided grid

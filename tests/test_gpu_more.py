@@ -1,5 +1,5 @@
 """GPU parity, second batch: hipGraph replay with moving primitives (BASELINE config 5), the paths that leave the
-fast kernel (column records that overflow, shadow rays that start in unoccupied bins), mouse pick."""
+wave kernel (column records that overflow, shadow rays that start in unoccupied bins), mouse pick."""
 import numpy as np
 import pytest
 
@@ -76,7 +76,7 @@ def test_overflowing_columns_take_the_generic_kernel(par, oracle, sprite, T):
 
 def test_shadow_rays_from_unoccupied_bins(par, oracle, T):
     # sprite depths far outside the box (and negative world z) put the ray's start bin where no primitive is:
-    # the fast kernel then walks per lane (trace_hash_for_light as written)
+    # the wave kernel then walks per lane (trace_hash_for_light as written)
     w, h, l = 480, 320, 320
     params = T.default_params(w, h, l)
     sprite = par.tile_floor()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase timing of columns_kernel / render_fast_kernel (PAR_DEBUG_STAMPS=1), GPU box."""
+"""Per-workgroup phase timing of the column records (columns_body) (PAR_DEBUG_STAMPS=1), GPU box."""
 import ctypes as C, importlib, os, sys
 os.environ["PAR_DEBUG_STAMPS"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,8 +25,7 @@ L_.par_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = L_.par_debug_read_stamps(r._ctx, buf.ctypes.data_as(C.c_void_p), n)
 assert rc == 0, rc
 st = buf.reshape(2, 8192, 8).astype(np.float64) * 0.01  # us (100 MHz)
-for k, name, labels in ((0, "columns_kernel", ["start", "listed", "A done", "B walks done", "end"]),
-                        (1, "render_fast_kernel", ["start", "staged", "1st rec in LDS", "1st column done", "end"])):
+for k, name, labels in ((0, "columns_body", ["start", "listed", "A done", "B walks done", "end"]),):
     x = st[k]
     live = x[:, 4] > 0
     x = x[live]
