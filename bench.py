@@ -259,7 +259,7 @@ def main():
             "note": "render_wave_kernel is VALU-issue/latency bound, not bandwidth bound (DESIGN.md section 5)",
             "kernels_ms": {"hash_build+columns (3 kernels)": round(avg["bin"], 5),
                            "fill_kernel": round(avg["fill"], 5),
-                           "render_wave_kernel+render_tiles_kernel": round(avg["render"], 5)},
+                           "render_wave_kernel+render_overflow_kernel": round(avg["render"], 5)},
             "fill_kernel": {"achieved": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9, 1),
                             "frac": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "whole_frame": {"achieved": round(bytes_frame / (ms_per_step * 1e-3) / 1e9, 1),

@@ -61,9 +61,10 @@ typedef struct par_frame_stats {
     int64_t bin_insertions;  /* (entity, bin) pairs inserted this frame (alt:243-267 iterations) */
     int64_t shadow_rays;     /* shadow rays traced (only with PAR_RENDER_COUNT_RAYS), else -1 */
     int64_t occupied_columns; /* screen columns (bin footprints) in the rendered rows that show a primitive */
+    int64_t overflow_columns; /* ... of which did not fit a column record (rendered straight from the hash) */
     float ms_bin;            /* device time of the hash build + column kernels of the last timed render, else -1 */
     float ms_fill;           /* device time of the background fill kernel of the last timed render, else -1 */
-    float ms_render;         /* device time of the two render kernels of the last timed render, else -1 */
+    float ms_render;         /* device time of the render kernel of the last timed render, else -1 */
 } par_frame_stats;
 
 const char* par_status_string(int status);

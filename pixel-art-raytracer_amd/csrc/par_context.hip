@@ -196,8 +196,6 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.row_begin = row_begin; a.row_end = row_end;
     a.by_lo = row_begin / B;
     a.by_hi = (row_end - 1) / B;
-    a.tile_rows = PAR_NT / B;
-    a.subs = c->grid.subs;
     a.set = set;
     // every ray traced (as the reference does), or the lit plane requested
     a.trace_bg = ((flags & PAR_RENDER_TRACE_BACKGROUND) || out.lit) ? 1 : 0;
@@ -385,10 +383,6 @@ int par_create(const par_params* params, int device, par_context** out) {
         const size_t bytes = (size_t)2 * PAR_STAMP_WGS * PAR_STAMP_SLOTS * sizeof(unsigned long long);
         if ((e = hipMalloc(&ctx->grid.stamps, bytes)) != hipSuccess) return bail(e);
         if ((e = hipMemset(ctx->grid.stamps, 0, bytes)) != hipSuccess) return bail(e);
-    }
-    {
-        const int tr = PAR_NT / p.bin_size;
-        ctx->grid.subs = (p.bin_size + tr - 1) / tr;
     }
     if ((e = hipMalloc(&ctx->grid.slow_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.bgwalk, (size_t)gx * sizeof(par_bgwalk))) != hipSuccess) return bail(e);
@@ -741,9 +735,11 @@ int par_get_stats(par_context* ctx, par_frame_stats* stats) {
     ctx->stats.bin_insertions = ctx->total_pairs;
     ctx->stats.shadow_rays = -1;
     {
-        int32_t nc = 0;
-        PAR_HIP(hipMemcpy(&nc, ctx->grid.counters + PAR_CNT_COLS, sizeof(nc), hipMemcpyDeviceToHost));
-        ctx->stats.occupied_columns = nc;
+        int32_t nc[2] = {0, 0};
+        static_assert(PAR_CNT_COLS == 0 && PAR_CNT_SLOW == 1, "read together");
+        PAR_HIP(hipMemcpy(nc, ctx->grid.counters, sizeof(nc), hipMemcpyDeviceToHost));
+        ctx->stats.occupied_columns = nc[0];
+        ctx->stats.overflow_columns = nc[1];
     }
     if (ctx->last_flags & PAR_RENDER_COUNT_RAYS) {
         unsigned long long v = 0;

@@ -21,18 +21,13 @@ constexpr int PAR_STAMP_SLOTS = 8;      // time stamps per workgroup in the debu
 constexpr int PAR_STAMP_WGS = 8192;     // workgroups per kernel that get a row in it
 
 // Kernel geometry (see DESIGN.md "kernels").
-constexpr int PAR_NT = 320;             // threads per render workgroup = 5 wavefronts, one pixel per thread
-constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count the LDS column list is sized for
-constexpr int PAR_MAX_ENTRIES = 256;    // column slot records staged in LDS (the rest is read from L2/HBM)
-constexpr int PAR_MAX_OCC = 512;        // shadow-occluder records staged in LDS per round
-constexpr int PAR_CHAIN_MAX = 1024;     // walk iterations whose bin coordinates are staged in LDS at a time
-constexpr int PAR_PPT = 3;              // shadow-walk probes per thread per batch
-// Per-column record built once per frame by columns_kernel and consumed by every tile of the column.
+constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count (bin coordinates are kept in int16)
+// Per-column record built once per frame by columns_kernel and consumed by every wavefront rendering the column.
 constexpr int PAR_COL_NB = 16;          // occupied bins of one column it can describe
 constexpr int PAR_COL_ENT = 48;         // slot records of one column
 constexpr int PAR_BIN_WALK = 64;        // occluder records of one start bin's shadow walk
 constexpr int PAR_COL_WALK = 160;       // occluder records of all walks of one column
-constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = PAR_NT / 2;  // bin sizes the tile mapping supports (>= 2 rows per tile)
+constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = 160;  // supported bin sizes
 
 // What the shading pass needs of a sprite texel besides its depth, in one 16-byte record: the normal (spr:70) and
 // the palette colour the texel's index resolves to (spr:68 through color_palette, alt:352-354). Built on the host
@@ -100,7 +95,6 @@ struct par_grid_dev {
     unsigned long long* stamps;  // debug (PAR_DEBUG_STAMPS=1): per workgroup phase time stamps, else nullptr
     int32_t capacity;
     int32_t col_capacity;
-    int32_t subs;             // tiles per column
 };
 
 struct par_bin_args {
@@ -115,11 +109,9 @@ struct par_render_args {
     int32_t W, H, B;
     int32_t row_begin, row_end;    // rows rendered by this launch
     int32_t by_lo, by_hi;          // bin rows touched
-    int32_t tile_rows;             // rows per workgroup tile: PAR_NT / B
-    int32_t subs;                  // tiles per bin row = ceil(B / tile_rows)
     int32_t set;                   // grid set of this frame
     int32_t trace_bg;              // 1: background shadow rays are traced too (flag, or lit plane requested)
-    int32_t dense;                 // 1: every column is rendered by render_tiles (every ray traced), no fill pass
+    int32_t dense;                 // 1 (PAR_FORCE_GENERIC=1, tests): every column is rendered as if it had no record
     uint32_t magic_b;              // floor(n / B) == __umulhi(n, magic_b) for n * B < 2^32
     float ambient;
     uint32_t background;           // gray level (alt:281)
@@ -149,10 +141,10 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
 // Column records + background fill in one launch when possible (else hipErrorNotSupported, nothing launched).
 hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                    hipStream_t stream);
-// Background for every pixel of the row range (skipped when a.dense); the render kernels then overwrite the tiles
-// primitives reach. Independent of the hash.
+// Background for every pixel of the row range; the render kernel then overwrites the pixels primitives cover.
+// Independent of the hash.
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
-// `column_bound`: an upper bound of the occupied columns (ignored when a.dense: every tile, generic kernel).
+// `column_bound`: an upper bound of the occupied columns.
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                              hipStream_t stream);
 

@@ -226,12 +226,6 @@ __device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum, int& total)
     return base + incl - v;
 }
 
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return v;
-}
-
 // std::min / std::max on floats: (b<a)?b:a and (a<b)?b:a -- the first argument survives a NaN (SURVEY a-5).
 __device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
@@ -261,25 +255,11 @@ __device__ __forceinline__ uint32_t color_scale(uint32_t c, float v) {
     return r | (g << 8) | (b << 16) | (c & 0xFF000000u);
 }
 
-// (sy, sz) of a start bin as one sortable word; bin coordinates are far inside +-16384 (positions are `short`,
-// bins at least 8 wide).
-__device__ __forceinline__ int pack_key(int sy, int sz) {
-    return (int)((((uint32_t)(sy + 16384) & 0x7FFFu) << 16) | ((uint32_t)(sz + 32768) & 0xFFFFu));
-}
-
 // Trunc-toward-zero division by the bin size through a precomputed reciprocal: exact for |n| * B < 2^32
 // (|n| <= 3 * 32767 here and B <= 320).
 __device__ __forceinline__ int div_bin(int n, uint32_t magic) {
     const int q = (int)__umulhi((uint32_t)(n < 0 ? -n : n), magic);
     return n < 0 ? -q : q;
-}
-
-// The XCD-aware workgroup remap: workgroups are dealt round-robin to the 8 XCDs (each with its own L2); giving
-// every XCD a CONTIGUOUS range of logical ids keeps neighbours (which share cache lines of the frame and of the
-// hash) in one L2. Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int b, int nb) {
-    const int q = nb >> 3, rem = nb & 7, xcd = b & 7;
-    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (b >> 3);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -709,19 +689,26 @@ __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, co
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// render_chunk: one pixel per lane, for up to 64 pixels of one column (wavefront level: no workgroup cooperation).
-// `rec_` is the column's record (in LDS or in global memory), `depth0` / `color0` sprite 0's depth and palette-index
-// tables (ditto). `own` >= 0: the lanes render the pixels entry `own` is the first to cover; -1: all pixels.
+// render_chunk: one pixel per lane, for up to 64 pixels of one column (wavefront level: no workgroup cooperation;
+// must be called by whole wavefronts). `rec_` is the column's record; `own` >= 0: the lanes render the pixels entry
+// `own` is the first to cover, -1: all pixels. `generic`: the column has no usable record (it overflowed one):
+// the primary pass then reads the column's bins straight from the hash, as the reference does, and every shadow
+// walk is done here.
 // ------------------------------------------------------------------------------------------------------------
-template <class ColorT>
+struct WaveScratch {  // per wavefront: what wave_walk needs
+    int16_t chain[3][65];
+    par_slot stage[PAR_BIN_WALK];
+};
+
+template <bool GENERIC>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
-                                             const int32_t* depth0, const ColorT* color0,
                                              const par_frame_dyn& dyn, int n_entries, int n_nb, int bx, int by,
-                                             int own, int col, int row, bool valid, int lane) {
+                                             int own, int col, int row, bool valid, int lane, WaveScratch* ws) {
     const int W = a.W, H = a.H;
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
-    // ---- primary ray, alt:271-397: the column's entries front to back as one flat list -----------------
+    const int32_t* depth0 = a.sprites[0].depth;
+    // ---- primary ray, alt:271-397: the column's slot records front to back ------------------------------------
     bool hit = false;
     int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;
     {
@@ -734,19 +721,14 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         bool hit_in_bin = false;
         bool done = !valid;
         int w_ybase = 0, w_pz = 0, w_d = 0;
-        for (int e = 0; e < n_entries; e++) {
-            const int bz = rec_.ebz[e];
-            const par_slot rec = rec_.entries[e];
-            if (bz != cur_bz) {  // the previous bin is complete
-                adjacent += hit_in_bin ? 1 : 0;      // alt:368
-                if (adjacent >= 2) done = true;      // alt:372-374
-                if (bz != cur_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
-                cur_bz = bz;
-                hit_in_bin = false;
-            }
-            // a lane whose pixel an earlier entry owns has nothing to do in this pass
-            if (first_cover < own) done = true;  // (never in tile mode: own = -1)
-            if (__all(done)) break;  // wavefront early-out
+        auto next_bin = [&](int bz) {  // the previous occupied bin is complete
+            adjacent += hit_in_bin ? 1 : 0;      // alt:368
+            if (adjacent >= 2) done = true;      // alt:372-374
+            if (bz != cur_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
+            cur_bz = bz;
+            hit_in_bin = false;
+        };
+        auto test = [&](const par_slot& rec, int e) {
             const int top = rec.py + rec.ey + rec.pz + rec.ez;
             if (!done && i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
                 first_cover = min(first_cover, e);
@@ -766,6 +748,26 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
                     hit_in_bin = true;                                        // alt:365
                 }
             }
+        };
+        if (!GENERIC) {  // the record's entries as one flat list
+            for (int e = 0; e < n_entries; e++) {
+                const int bz = rec_.ebz[e];
+                const par_slot rec = rec_.entries[e];
+                if (bz != cur_bz) next_bin(bz);
+                // a lane whose pixel an earlier entry owns has nothing to do in this pass
+                if (first_cover < own) done = true;  // (never in tile mode: own = -1)
+                if (__all(done)) break;  // wavefront early-out
+                test(rec, e);
+            }
+        } else {  // the column's bins as they lie in the hash, alt:292-376
+            const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
+            for (int bz = 0; bz < g.gz; bz++) {
+                const int c = a.count[col_base + bz];  // (wave-uniform)
+                if (c == 0) continue;
+                next_bin(bz);
+                if (__all(done)) break;
+                for (int k = 0; k < c; k++) test(a.slots[(size_t)(col_base + bz) * PAR_SLOTS + k], 0);
+            }
         }
         // an entry pass renders the pixels entry `own` is the first to cover; a tile pass renders them all
         valid = valid && (own < 0 || first_cover == own);
@@ -776,41 +778,40 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         }
     }
 
-    // ---- shading, alt:704-758 --------------------------------------------------------------------------
+    // ---- shading, alt:704-758 ---------------------------------------------------------------------------------
     float nx = 0.f, ny = 0.f, nz = 0.f;
     uint32_t rgba = bg_rgba;
     int pal_index = PAR_PALIDX_BACKGROUND;
     float bright = ambient;
-    bool lit_px = true;
-    if (hit && !(a.flags & (1u << 26))) {  // bit 26: ablation (timing experiments only), no shading
+    bool lit = true;
+    const bool shade = hit && !(a.flags & (1u << 26));  // bit 26: ablation (timing experiments only), no shading
+    bool need_walk = false;  // the shadow ray still has to be resolved
+    float inv_x = 0.f, inv_y = 0.f, inv_z = 0.f, b_lit = 0.f;
+    int sy = 0, sz = 0, ox = 0, oy = 0, oz = 0;
+    if (shade) {
         // normal (alt:349-350) + resolved palette colour (alt:352-354)
         const par_texel ti = a.texinfo[p_tex];
         nx = ti.nx; ny = ti.ny; nz = ti.nz;
         rgba = ti.rgba;
         if (a.out.palidx) {
-            if (p_tex < PAR_SPRITE_TEXELS) {
-                pal_index = (int)color0[p_tex];
-            } else {
-                const int sid = p_tex / PAR_SPRITE_TEXELS;
-                pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
-            }
+            const int sid = p_tex / PAR_SPRITE_TEXELS;
+            pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
         }
         const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
         // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
         const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
         const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
         const float tx = dx / len, ty = dy / len, tz = dz / len;
-        const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
+        inv_x = 1.f / tx; inv_y = 1.f / ty; inv_z = 1.f / tz;              // alt:717-719
         const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
         const float diffuse = std_max(0.f, dot);                           // alt:745
-        const float b_lit = std_min(1.f, diffuse + ambient);               // alt:758
-        const int sy = div_bin(H - wy - wz, a.magic_b);                    // alt:725-726
-        const int sz = div_bin(wz, a.magic_b);                             // alt:727
-        const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
-        // shadow ray, alt:738-742: the walk from the start bin was done by columns_kernel
-        bool lit = true;
+        b_lit = std_min(1.f, diffuse + ambient);                           // alt:758
+        sy = div_bin(H - wy - wz, a.magic_b);                              // alt:725-726
+        sz = div_bin(wz, a.magic_b);                                       // alt:727
+        ox = (int)(int16_t)col; oy = (int)(int16_t)p_y; oz = (int)(int16_t)p_z;  // alt:720-722
+        // shadow ray, alt:738-742: columns_kernel has walked from every occupied bin of the column
         int wi = -1;
-        if (sy == by) {
+        if (!GENERIC && sy == by) {
             for (int n = 0; n < n_nb; n++) {
                 if (rec_.nb[n].bz == sz) wi = n;
             }
@@ -824,22 +825,54 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
                     break;
                 }
             }
+        } else if (GENERIC) {
+            need_walk = true;
         } else {
-            lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y,
-                                   inv_z);
+            // a start bin that holds no primitive (negative world z, sprite depths outside the box) has no
+            // precomputed walk: trace_hash_for_light as written, per lane
+            lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y, inv_z);
         }
-        bright = lit ? b_lit : ambient;
-        lit_px = lit;
     }
+    if (GENERIC) {
+        // No precomputed walks: the wavefront walks once per distinct start bin among its lanes; every lane of that
+        // bin then tests the staged records.
+        for (unsigned long long pending = __ballot(need_walk); pending; pending = __ballot(need_walk)) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int gsy = __shfl(sy, leader), gsz = __shfl(sz, leader);
+            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, gsy, gsz, ws->chain, ws->stage);
+            if (need_walk && sy == gsy && sz == gsz) {
+                if (n_rec >= 0) {
+                    for (int r = 0; r < n_rec; r++) {
+                        const par_slot rec = ws->stage[r];
+                        if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
+                            lit = false;
+                            break;
+                        }
+                    }
+                } else {  // more records on the way than the stage holds: per lane, as the reference writes it
+                    lit = lane_shadow_walk(g, a.count, a.slots, bx, sy, sz, dyn, p_entity, ox, oy, oz, inv_x, inv_y,
+                                           inv_z);
+                }
+                need_walk = false;
+            }
+            // the next walk overwrites the stage: every lane has read it (LDS operations of one wavefront complete
+            // in order; keep the compiler from moving them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    if (shade) bright = lit ? b_lit : ambient;
+    const bool lit_px = lit;
     if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
         const unsigned long long m = __ballot(valid && hit);
         if (lane == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
     }
 
-    // ---- quantise + store, alt:735, 757-758 ------------------------------------------------------------
+    // ---- quantise + store, alt:735, 757-758 -------------------------------------------------------------------
     if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
         asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
-    } else if (valid && hit) {  // (uncovered pixels keep what fill_kernel wrote)
+    } else if (valid && hit) {  // (uncovered pixels keep what the fill wrote)
         const size_t o = (size_t)(row - a.row_begin) * W + col;
         if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
         if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
@@ -874,32 +907,30 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
 // (Measured against persistent 5-wavefront workgroups with LDS-staged records and sprite tables, 4096^2 / 1024
 // primitives: 32 instead of 46 us alone, 40 instead of 50 us per frame with three frames in flight.)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_wave_kernel(par_grid_dev g, par_render_args a,
-                                                                          int cost_per_part) {
+template <bool GENERIC>
+__device__ __forceinline__ void render_column(const par_grid_dev& g, const par_render_args& a, int ci, int part,
+                                              int max_parts, int cost_per_part, WaveScratch* ws) {
     const int lane = (int)threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int ci = (int)blockIdx.x;
-    if (ci >= g.col_capacity) return;
-    const int n_cols = g.counters[PAR_CNT_COLS];
     const par_colrec& rec_ = g.colrec[ci];
-    const int n_entries_rec = rec_.n_entries, n_nb = rec_.n_nb, overflow = rec_.overflow;
+    const int n_entries_rec = rec_.n_entries, n_nb = rec_.n_nb;
     const int bx = rec_.bx, by = rec_.by;
-    const bool tile_mode = rec_.tile_mode != 0;
+    const bool tile_mode = GENERIC || rec_.tile_mode != 0;
     const uint64_t dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
-    if (ci >= n_cols || overflow) return;
+    if (!GENERIC && rec_.overflow) return;  // render_overflow_kernel's
     // a column's chunks are shared by as many workgroups as its work is worth (the others of its row leave at once)
     const int col_parts =
-        min((int)gridDim.y, max(1, (rec_.chunks * (n_entries_rec + PAR_WAVE_CHUNK_COST) + cost_per_part - 1) / cost_per_part));
-    if ((int)blockIdx.y >= col_parts) return;
-    const int n_workers = col_parts * PAR_WAVE_NW, worker = (int)blockIdx.y * PAR_WAVE_NW + wave;
-    const int n_entries = (a.flags & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing experiments only)
+        GENERIC ? max_parts
+                : min(max_parts, max(1, (rec_.chunks * (n_entries_rec + PAR_WAVE_CHUNK_COST) + cost_per_part - 1) /
+                                            cost_per_part));
+    if (part >= col_parts) return;
+    const int n_workers = col_parts * PAR_WAVE_NW, worker = part * PAR_WAVE_NW + wave;
+    const int n_entries = (GENERIC || (a.flags & (1u << 24))) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
     const int W = a.W, H = a.H, B = a.B;
     const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
     const int c0 = bx * B;
     const int tw = min(B, W - c0);
     const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
-    const int32_t* depth0 = a.sprites[0].depth;
-    const int32_t* color0 = a.sprites[0].color;
     int k = 0;  // chunks of the column so far (wave-uniform)
     const int n_pass = tile_mode ? 1 : n_entries;
     for (int q = 0; q < n_pass; q++) {
@@ -934,372 +965,34 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_wave_kernel(par_grid_
             const int pidx = c * 64 + lane;
             const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
             const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
-            render_chunk(g, a, rec_, depth0, color0, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane);
+            render_chunk<GENERIC>(g, a, rec_, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane,
+                                  ws ? ws + wave : nullptr);
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// render_tiles_kernel: one workgroup (5 wavefronts, one pixel per lane) per tile of an occupied screen column;
-// a tile is B pixels wide and PAR_NT / B rows tall (40 x 8 for the reference's bin size).
-// ------------------------------------------------------------------------------------------------------------
-
-struct TileShared {
-    par_slot entries[PAR_MAX_ENTRIES];         // the column's slot records, ordered by (bin_z, slot)
-    par_slot occ[PAR_MAX_OCC];                 // shadow-occluder candidates of the current probe batch
-    int32_t sprite_depth[PAR_SPRITE_TEXELS];   // depth table of sprite 0 (the hot lookup of the primary pass)
-    int16_t nb_bz[PAR_MAX_GRID_DIM];           // non-empty bins of the column: bin_z ...
-    int16_t nb_off[PAR_MAX_GRID_DIM];          // ... first entry
-    uint8_t nb_cnt[PAR_MAX_GRID_DIM];          // ... visible count
-    int16_t chain[3][PAR_CHAIN_MAX + 1];       // truncated bin coordinates of the walk, per axis
-    int32_t wsum[PAR_NT / 64];
-    int32_t gkey[2];
-    int32_t nocc[3];
-};
-
-__device__ void render_tile_generic(const par_grid_dev& g, const par_render_args& a, TileShared& sm, int bx, int by,
-                                    int sub) {
-    const int tid = threadIdx.x;
-    const int W = a.W, H = a.H, B = a.B;
-    const int tile_r0 = by * B + sub * a.tile_rows;
-    const int r0 = max(tile_r0, a.row_begin);
-    const int r1 = min(min(tile_r0 + a.tile_rows, (by + 1) * B), min(H, a.row_end));
-    if (r0 >= r1) return;
-    const int c0 = bx * B;
-    const int tw = min(B, W - c0);
-    const bool trace_bg = (a.flags & PAR_RENDER_TRACE_BACKGROUND) != 0 || a.out.lit != nullptr;
-    const float ambient = a.ambient;
-    const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
-    const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
-    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
-
-    if (tid == 0) {
-        sm.gkey[0] = INT_MAX;
-        sm.gkey[1] = INT_MAX;
-        sm.nocc[0] = 0;
-        sm.nocc[1] = 0;
-        sm.nocc[2] = 0;
-    }
-    // sprite 0's depth table -> LDS (3.2 KB, read by every covered pixel in the primary pass)
-    for (int t = tid; t < PAR_SPRITE_TEXELS; t += PAR_NT) sm.sprite_depth[t] = a.sprites[0].depth[t];
-
-    // ---- phase 1: the column (bx, by, *) -> ordered list of non-empty bins and their slot records in LDS -----
-    // Lane t reads the count of bin_z = t and, without waiting for it, the bin's first slot record: most occupied
-    // bins hold a single primitive, so the record is already there when the count arrives.
-    // While copying, each lane also checks whether its records can cover any pixel of THIS tile.
-    const int wj_hi = H - r0, wj_lo = H - r1 + 1;  // world_j range of the tile's rows (alt:280)
-    int nb_base = 0, ent_base = 0;
-    int covers = 0;
-    for (int t0 = 0; t0 < g.gz; t0 += PAR_NT) {
-        const int t = t0 + tid;
-        const par_slot* src = a.slots + (size_t)(col_base + min(t, g.gz - 1)) * PAR_SLOTS;
-        const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;  // consecutive bytes: coalesced
-        const par_slot first = src[0];
-        int total;
-        const int packed = block_excl_scan<PAR_NT / 64>(((c != 0) << 16) | c, sm.wsum, total);
-        const int nb_i = nb_base + (packed >> 16);
-        const int off = ent_base + (packed & 0xFFFF);
-        if (c != 0) {
-            sm.nb_bz[nb_i] = (int16_t)t;
-            sm.nb_off[nb_i] = (int16_t)off;
-            sm.nb_cnt[nb_i] = (uint8_t)c;
-            for (int k = 0; k < c; k++) {
-                const par_slot rec = (k == 0) ? first : src[k];
-                if (off + k < PAR_MAX_ENTRIES) sm.entries[off + k] = rec;
-                // alt:310-317 over the tile's pixel rectangle
-                covers |= (rec.px < c0 + tw) && (rec.px + rec.ex > c0) && (wj_hi > rec.py + rec.pz) &&
-                          (wj_lo <= rec.py + rec.ey + rec.pz + rec.ez);
-            }
-        }
-        nb_base += total >> 16;
-        ent_base += total & 0xFFFF;
-    }
-    const int n_nb = nb_base;
-    // barrier for the LDS lists; it also tells whether any record can cover a pixel of this tile
-    const int any_cover = __syncthreads_or(covers);
-
-    // ---- this lane's pixel ----------------------------------------------------------------------------------
-    const int py = (int)__umulhi((uint32_t)tid, a.magic_b);
-    const int px = tid - py * B;
-    const int col = c0 + px, row = tile_r0 + py;
-    const bool valid = (px < tw) && (row >= r0) && (row < r1);
-    const size_t o = (size_t)(row - a.row_begin) * W + col;
-
-    if (!any_cover && !trace_bg) {
-        // nothing in this column reaches this tile: background (alt:281 -> alt:735), and no shadow ray to skip
-        if (valid) {
-            if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(bg_rgba, ambient);
-            if (a.out.palidx) a.out.palidx[o] = PAR_PALIDX_BACKGROUND;
-            if (a.out.brightness) a.out.brightness[o] = ambient;
-            if (a.out.gbuf) {
-                par_pixel bgp;
-                bgp.normal = par_vec3{0.f, 0.f, 0.f};
-                bgp.color.red = bgp.color.green = bgp.color.blue = (uint8_t)a.background;
-                bgp.color.alpha = 0;
-                bgp.y = 0; bgp.z = 0; bgp.entity_index = 0;
-                a.out.gbuf[o] = bgp;
-            }
-        }
-        return;
-    }
-
-    // ---- phase 2: primary ray, alt:271-397 -----------------------------------------------------------------
-    bool hit = false;
-    int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;  // background texel: y = z = 0, entity_index 0 (alt:281)
-    {
-        const int i = col;
-        const int world_j = (int)(int16_t)(H - row);  // alt:280
-        int adjacent = 0;                             // alt:282
-        int closest = INT_MIN;                        // alt:289
-        int prev_bz = -2;
-        bool done = !valid;
-        int w_ybase = 0, w_pz = 0, w_d = 0;
-        for (int n = 0; n < n_nb; n++) {
-            if (__all(done)) break;  // wavefront early-out: every lane has its two adjacent hit bins (alt:372-374)
-            const int bz = sm.nb_bz[n];
-            const int cnt = sm.nb_cnt[n];
-            const int off = sm.nb_off[n];
-            if (!done) {
-                if (bz != prev_bz + 1) adjacent = 0;  // an empty bin lies in between (alt:298-300)
-                prev_bz = bz;
-                bool hit_in_bin = false;
-                for (int s = 0; s < cnt; s++) {
-                    const int ei = off + s;
-                    const par_slot rec = (ei < PAR_MAX_ENTRIES) ? sm.entries[ei]
-                                                                : a.slots[(size_t)(col_base + bz) * PAR_SLOTS + s];
-                    const int top = rec.py + rec.ey + rec.pz + rec.ez;
-                    if (i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
-                        const int sprite_row = top - world_j;                         // alt:324-326
-                        const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
-                        const int sid = a.sprite_ids ? a.sprite_ids[rec.entity] : 0;  // alt:321-322
-                        const int d = (sid == 0) ? sm.sprite_depth[t] : a.sprites[sid].depth[t];
-                        const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
-                        if (closest >= depth) continue;                               // alt:344-346
-                        closest = depth;
-                        w_ybase = rec.py + rec.ey + rec.ez - sprite_row;              // alt:356-359
-                        w_pz = rec.pz;                                                // alt:360-361
-                        w_d = d;
-                        p_entity = rec.entity;                                        // alt:363
-                        p_tex = sid * PAR_SPRITE_TEXELS + t;
-                        hit = true;
-                        hit_in_bin = true;                                            // alt:365
-                    }
-                }
-                adjacent += hit_in_bin ? 1 : 0;  // alt:368
-                if (adjacent >= 2) done = true;  // alt:372-374
-            }
-        }
-        if (hit) {
-            p_y = w_ybase - w_d;
-            p_z = w_pz + w_d;
-        }
-    }
-    if (a.flags & (1u << 29)) hit = false;  // ablation (timing experiments only): drop the primary result
-
-    // ---- phase 3: shading set-up, alt:704-735 --------------------------------------------------------------
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    uint32_t rgba = bg_rgba;
-    int pal_index = PAR_PALIDX_BACKGROUND;
-    if (hit) {
-        const par_texel ti = a.texinfo[p_tex];  // normal (alt:349-350) + resolved palette colour (alt:352-354)
-        nx = ti.nx; ny = ti.ny; nz = ti.nz;
-        rgba = ti.rgba;
-        if (a.out.palidx) {
-            const int sid = p_tex / PAR_SPRITE_TEXELS;
-            pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
-        }
-    } else {
-        p_entity = 0; p_y = 0; p_z = 0;
-    }
-    bool pend = valid && (hit || trace_bg);
-    bool lit = true;
-    // A background pixel whose shadow ray is skipped keeps brightness = ambient: with a zero normal
-    // min(1, max(0, 0 * t) + ambient) is ambient whether or not the light is reached (SURVEY a-6).
-    float inv_x = 0.f, inv_y = 0.f, inv_z = 0.f, b_lit = ambient;
-    int key = INT_MAX;
-    if (pend) {
-        const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
-        // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
-        const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
-        const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
-        const float tx = dx / len, ty = dy / len, tz = dz / len;
-        inv_x = 1.f / tx;  // alt:717-719
-        inv_y = 1.f / ty;
-        inv_z = 1.f / tz;
-        const float dot = nx * tx + ny * ty + nz * tz;   // alt:746-747 (no contraction)
-        const float diffuse = std_max(0.f, dot);         // alt:745
-        b_lit = std_min(1.f, diffuse + ambient);         // alt:758
-        const int sy = div_bin(H - wy - wz, a.magic_b);  // alt:725-726
-        const int sz = div_bin(wz, a.magic_b);           // alt:727
-        key = pack_key(sy, sz);
-    }
-    if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
-        const unsigned long long m = __ballot(pend);
-        if ((tid & 63) == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
-    }
-    const int ox = (int)(int16_t)col, oy = (int)(int16_t)p_y, oz = (int)(int16_t)p_z;  // alt:720-722
-
-    // ---- phase 4: shadow rays, alt:738-742 + alt:399-500 ---------------------------------------------------
-    // Pixels of the tile whose walk starts in the same bin visit the same bins (the probe sequence depends only on
-    // the start and light bins), so the walk is done once per distinct start bin by the whole workgroup; the
-    // occupied bins it finds are staged in LDS and every pixel of the group slab-tests that list. The result of
-    // trace_hash_for_light is an OR over probes, hence independent of probe order and of duplicate probes.
-    int batch = 0;  // running batch number: selects the nocc slot
-    for (int iter = 0;; iter++) {
-        if (a.flags & (1u << 30)) break;  // ablation (timing experiments only): no shadow pass
-        const int mykey = wave_min(pend ? key : INT_MAX);
-        if ((tid & 63) == 0 && mykey != INT_MAX) atomicMin(&sm.gkey[iter & 1], mykey);
-        if (tid == 0) sm.gkey[(iter + 1) & 1] = INT_MAX;
-        __syncthreads();
-        const int cur = sm.gkey[iter & 1];
-        if (cur == INT_MAX) break;  // uniform
-
-        const int sx = bx;  // world_x / B, alt:724
-        const int sy = (cur >> 16) - 16384;
-        const int sz = (cur & 0xFFFF) - 32768;
-        const bool mine = pend && key == cur;
-
-        // alt:406-430
-        const float fsx = (float)sx, fsy = (float)sy, fsz = (float)sz;
-        const float ddx = (float)dyn.lbx - fsx, ddy = (float)dyn.lby - fsy, ddz = (float)dyn.lbz - fsz;
-        float largest = __builtin_fabsf(ddx);
-        if (largest < __builtin_fabsf(ddy)) largest = __builtin_fabsf(ddy);
-        if (largest < __builtin_fabsf(ddz)) largest = __builtin_fabsf(ddz);
-        const int m = (int)largest;  // alt:432
-        const int start_idx = flat_index(g.gy, g.gz, sx, sy, sz);
-        const float step_mine = ((tid == 0) ? ddx : ((tid == 1) ? ddy : ddz)) / largest;  // alt:423-425
-        float carry = (tid == 0) ? fsx : ((tid == 1) ? fsy : fsz);
-        bool group_done = false;
-
-        for (int it0 = 0; it0 < m && !group_done; it0 += PAR_CHAIN_MAX) {
-            const int n_it = min(PAR_CHAIN_MAX, m - it0);
-            // the float accumulation of the walk (alt:436-466) is inherently serial: three lanes, one per axis
-            if (tid < 3) {
-                float v = carry;
-                sm.chain[tid][0] = (int16_t)(int)v;  // alt:468: truncation toward zero
-                for (int s = 1; s <= n_it; s++) {
-                    v = v + step_mine;
-                    sm.chain[tid][s] = (int16_t)(int)v;
-                }
-                carry = v;
-            }
-            __syncthreads();
-
-            // The 7 probes of one walk iteration (alt:438-466) are the corners of the 2x2x2 block spanned by
-            // bin(tmp) and bin(tmp + step), minus bin(tmp) itself.
-            const int n_probe = 7 * n_it;
-            for (int pb = 0; pb < n_probe && !group_done; pb += PAR_NT * PAR_PPT, batch++) {
-                const int slot = batch % 3;
-                if (tid == 0) sm.nocc[(batch + 1) % 3] = 0;
-                int idx[PAR_PPT], cnt[PAR_PPT], pos[PAR_PPT];
-#pragma unroll
-                for (int j = 0; j < PAR_PPT; j++) {
-                    const int pid = pb + j * PAR_NT + tid;
-                    cnt[j] = 0;
-                    idx[j] = 0;
-                    if (pid < n_probe) {
-                        const int li = pid / 7, mask = pid - li * 7 + 1;
-                        const int ax = sm.chain[0][li], ay = sm.chain[1][li], az = sm.chain[2][li];
-                        const int qx = sm.chain[0][li + 1], qy = sm.chain[1][li + 1], qz = sm.chain[2][li + 1];
-                        // a probe whose stepped axes do not all change bin repeats another probe of this
-                        // iteration (or the previous iteration's last bin): skip it
-                        const bool canonical = (!(mask & 1) || qx != ax) && (!(mask & 2) || qy != ay) &&
-                                               (!(mask & 4) || qz != az);
-                        if (canonical) {
-                            const int b = flat_index(g.gy, g.gz, (mask & 1) ? qx : ax, (mask & 2) ? qy : ay,
-                                                     (mask & 4) ? qz : az);
-                            // alt:471-473: the start bin is skipped; an out-of-range flat index reads as an empty
-                            // bin (the reference reads past its array there, alt:476)
-                            if (b != start_idx && b >= 0 && b < g.volume) {
-                                idx[j] = b;
-                                cnt[j] = a.count[b];
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < PAR_PPT; j++) pos[j] = cnt[j] ? atomicAdd(&sm.nocc[slot], cnt[j]) : 0;
-                __syncthreads();
-                const int total = sm.nocc[slot];
-                if (total == 0) continue;  // uniform: nothing in the way in these bins
-                for (int base = 0; base < total; base += PAR_MAX_OCC) {
-#pragma unroll
-                    for (int j = 0; j < PAR_PPT; j++) {
-                        for (int k = 0; k < cnt[j]; k++) {
-                            const int o = pos[j] + k - base;
-                            if (o >= 0 && o < PAR_MAX_OCC) sm.occ[o] = a.slots[(size_t)idx[j] * PAR_SLOTS + k];
-                        }
-                    }
-                    __syncthreads();
-                    const int nrec = min(PAR_MAX_OCC, total - base);
-                    bool live = mine && lit;
-                    for (int r = 0; r < nrec; r++) {
-                        if (!__any(live)) break;  // wavefront early-out: all lanes shadowed or not in the group
-                        const par_slot rec = sm.occ[r];
-                        if (live && rec.entity != p_entity &&                  // alt:484-487
-                            slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:489-491
-                            lit = false;
-                            live = false;
-                        }
-                    }
-                    // barrier before occ is overwritten; on the last round it also tells whether anyone is lit
-                    if (base + PAR_MAX_OCC < total) {
-                        __syncthreads();
-                    } else if (!__syncthreads_or((mine && lit) ? 1 : 0)) {
-                        group_done = true;  // every pixel of the group is shadowed: stop walking
-                    }
-                }
-            }
-        }
-        pend = pend && !mine;
-        __syncthreads();
-    }
-
-    // ---- phase 5: quantise + store, alt:735, 757-758 --------------------------------------------------------
-    if (!valid) return;
-    const float bright = lit ? b_lit : ambient;
-    if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
-    if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
-    if (a.out.brightness) a.out.brightness[o] = bright;
-    if (a.out.lit) a.out.lit[o] = lit ? 1 : 0;
-    if (a.out.gbuf) {
-        par_pixel px;
-        px.normal = par_vec3{nx, ny, nz};
-        px.color.red = (uint8_t)(rgba & 0xFF);
-        px.color.green = (uint8_t)((rgba >> 8) & 0xFF);
-        px.color.blue = (uint8_t)((rgba >> 16) & 0xFF);
-        px.color.alpha = (uint8_t)(rgba >> 24);
-        px.y = p_y;
-        px.z = p_z;
-        px.entity_index = p_entity;
-        a.out.gbuf[o] = px;
-    }
+__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_wave_kernel(par_grid_dev g, par_render_args a,
+                                                                          int cost_per_part) {
+    const int ci = (int)blockIdx.x;
+    if (ci >= g.counters[PAR_CNT_COLS] || ci >= g.col_capacity) return;
+    render_column<false>(g, a, ci, (int)blockIdx.y, (int)gridDim.y, cost_per_part, nullptr);
 }
 
-// The generic tile kernel: the tiles of overflowed columns (work list), or every tile of the row range when every
-// ray is traced as the reference does (a.dense). Workgroups stride over the tiles when the grid was capped.
-__global__ __launch_bounds__(PAR_NT) void render_tiles_kernel(par_grid_dev g, par_render_args a) {
-    __shared__ TileShared sm;
+// The columns that overflowed their record (columns_kernel lists them), or every column when a.dense
+// (PAR_FORCE_GENERIC=1, tests): the primary pass reads the column's bins straight from the hash, as the reference
+// does, and the shadow walks are done here, once per wavefront and distinct start bin. A rare path: the launch is
+// small and its workgroups leave at once when the list is empty.
+__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_overflow_kernel(par_grid_dev g, par_render_args a) {
+    __shared__ WaveScratch scratch[PAR_WAVE_NW];
+    const int n_cols = min(g.counters[PAR_CNT_COLS], g.col_capacity);
     if (a.dense) {
-        const int total = g.gx * (a.by_hi - a.by_lo + 1) * a.subs;
-        const bool one_pass = (int)gridDim.x == total;
-        for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
-            const int wg = one_pass ? xcd_remap(w, total) : w;
-            const int ci = wg / a.subs, sub = wg - ci * a.subs;
-            const int by = a.by_lo + ci / g.gx;  // x fastest: neighbours in x share lines of the frame
-            const int bx = ci - (ci / g.gx) * g.gx;
-            render_tile_generic(g, a, sm, bx, by, sub);
-            __syncthreads();
+        for (int ci = (int)blockIdx.x; ci < n_cols; ci += (int)gridDim.x) {
+            render_column<true>(g, a, ci, (int)blockIdx.y, (int)gridDim.y, 1, scratch);
         }
     } else {
-        // the columns whose record overflowed: every tile of theirs in the row range
         const int n_slow = g.counters[PAR_CNT_SLOW];
-        for (int w = (int)blockIdx.x; w < n_slow * a.subs; w += (int)gridDim.x) {
-            const int k = w / a.subs, sub = w - k * a.subs;
-            const int col = g.col_list[g.slow_list[k]];
-            const int bx = col / g.gy, by = col - (col / g.gy) * g.gy;
-            render_tile_generic(g, a, sm, bx, by, sub);
-            __syncthreads();
+        for (int s = (int)blockIdx.x; s < n_slow; s += (int)gridDim.x) {
+            render_column<true>(g, a, g.slow_list[s], (int)blockIdx.y, (int)gridDim.y, 1, scratch);
         }
     }
 }
@@ -1332,7 +1025,6 @@ hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, 
 
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                               hipStream_t stream) {
-    if (a.dense) return hipSuccess;
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     int64_t blocks = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (blocks < 0) blocks = 0;
@@ -1351,7 +1043,7 @@ hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args&
                                    hipStream_t stream) {
     const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
     const bool pal_fast = !a.out.palidx || ((a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0));
-    if (a.dense || a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) {
+    if (a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) {
         return hipErrorNotSupported;
     }
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
@@ -1371,7 +1063,6 @@ hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args&
 }
 
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream) {
-    if (a.dense) return hipSuccess;
     // Color{127,127,127,0} * ambient, spr:8-16 (same truncation on the host)
     const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);
     const uint32_t out_rgba = ch | (ch << 8) | (ch << 16);
@@ -1408,12 +1099,6 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                              hipStream_t stream) {
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
-    const int64_t tiles_in_range = cols_in_range * a.subs;
-    if (tiles_in_range <= 0 || tiles_in_range > 0x7FFFFFFF) return hipErrorInvalidValue;
-    if (a.dense) {
-        hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)tiles_in_range), dim3(PAR_NT), 0, stream, g, a);
-        return hipGetLastError();
-    }
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound <= 0) return hipSuccess;
     // gridDim.y workgroups per column (a column uses as many as its work is worth); few columns: more of them, and
@@ -1421,11 +1106,14 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     // frames in flight / one): y=1: 38.6 / 72.8 us, y=2: 39.9 / 66.0, y=4: 41.1 / 64.8, y=8: 44.3 / 64.9.
     const int parts = bound >= 2048 ? 2 : (bound >= 512 ? 4 : 8);
     const int cost_per_part = bound >= 2048 ? 100 : (bound >= 512 ? 50 : 25);
-    hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0, stream, g,
-                       a, cost_per_part);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    // overflowed columns are the exception: a small strided grid
-    hipLaunchKernelGGL(render_tiles_kernel, dim3((unsigned)(bound < 256 ? bound : 256)), dim3(PAR_NT), 0, stream, g, a);
+    if (!a.dense) {
+        hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0,
+                           stream, g, a, cost_per_part);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    // overflowed columns are the exception: a small strided grid (up to 8 workgroups share a column)
+    const int64_t oblocks = a.dense ? (bound < 1024 ? bound : 1024) : (bound < 32 ? bound : 32);
+    hipLaunchKernelGGL(render_overflow_kernel, dim3((unsigned)oblocks, 8u), dim3(PAR_WAVE_NW * 64), 0, stream, g, a);
     return hipGetLastError();
 }
