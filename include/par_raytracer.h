@@ -64,7 +64,8 @@ typedef struct par_frame_stats {
     int64_t overflow_columns; /* ... of which did not fit a column record (rendered straight from the hash) */
     float ms_bin;            /* device time of the hash build + column kernels of the last timed render, else -1 */
     float ms_fill;           /* device time of the background fill kernel of the last timed render, else -1 */
-    float ms_render;         /* device time of the render kernel of the last timed render, else -1 */
+    float ms_render;         /* device time of the render kernel (render_wave_kernel) of the last timed render, else -1 */
+    float ms_overflow;       /* device time of the overflow-column kernel of the last timed render, else -1 */
 } par_frame_stats;
 
 const char* par_status_string(int status);
@@ -111,7 +112,7 @@ int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outp
 int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
                       unsigned flags);
 /* As par_render_device, bracketing the kernel groups with HIP events on `stream`; blocks until the frame is done
- * and fills stats->ms_bin (hash build + column kernels) / ms_fill / ms_render (the two render kernels). */
+ * and fills stats->ms_bin (hash build + column kernels) / ms_fill / ms_render / ms_overflow. */
 int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int row_end,
                             const par_outputs* device_out, unsigned flags, par_frame_stats* stats);
 

@@ -57,7 +57,7 @@ struct par_context {
     int graph_set = 0;
     int64_t graph_pair_bound = 0;  // (entity, bin) pairs a captured graph's launch grids can take
 
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     par_frame_stats stats{};
     unsigned last_flags = 0;
     std::string err;
@@ -199,7 +199,7 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.set = set;
     // every ray traced (as the reference does), or the lit plane requested
     a.trace_bg = ((flags & PAR_RENDER_TRACE_BACKGROUND) || out.lit) ? 1 : 0;
-    // PAR_FORCE_GENERIC=1 (testing): every tile goes through the self-contained generic kernel
+    // PAR_FORCE_GENERIC=1 (testing): every column goes through render_overflow_kernel
     static const bool force_generic = [] { const char* e = std::getenv("PAR_FORCE_GENERIC"); return e && e[0] == '1'; }();
     a.dense = force_generic ? 1 : 0;
     a.magic_b = (uint32_t)((1ull << 32) / (uint64_t)B + 1ull);
@@ -281,6 +281,8 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     if (!merged) PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
+    if (ev) PAR_HIP(hipEventRecord(ev[4], stream));
+    PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
 }
@@ -364,6 +366,7 @@ int par_create(const par_params* params, int device, par_context** out) {
     ctx->gx = gx; ctx->gy = gy; ctx->gz = gz; ctx->volume = gx * gy * gz;
     ctx->grid.gx = gx; ctx->grid.gy = gy; ctx->grid.gz = gz; ctx->grid.volume = ctx->volume;
     ctx->stats.shadow_rays = -1; ctx->stats.ms_bin = -1.f; ctx->stats.ms_fill = -1.f; ctx->stats.ms_render = -1.f;
+    ctx->stats.ms_overflow = -1.f;
     auto bail = [&](hipError_t e) {
         int rc = e == hipErrorOutOfMemory ? PAR_ERR_OOM : PAR_ERR_HIP;
         par_destroy(ctx);
@@ -395,7 +398,7 @@ int par_create(const par_params* params, int device, par_context** out) {
     if ((e = hipMalloc(&ctx->d_dyn, sizeof(par_frame_dyn))) != hipSuccess) return bail(e);
     if ((e = hipMemcpy(ctx->d_palette, p.palette, PAR_MAX_PALETTE * sizeof(par_color), hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if ((e = hipMemset(ctx->grid.slots, 0, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 5; i++) {
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return bail(e);
     }
     if (reset_grid(ctx) != PAR_OK) {
@@ -436,7 +439,7 @@ void par_destroy(par_context* ctx) {
     }
     if (ctx->pin_aabbs) (void)hipHostFree(ctx->pin_aabbs);
     if (ctx->pin_dyn) (void)hipHostFree(ctx->pin_dyn);
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 5; i++) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -633,7 +636,8 @@ int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int r
     PAR_HIP(hipEventSynchronize(ctx->ev[2]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_bin, ctx->ev[0], ctx->ev[1]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_fill, ctx->ev[1], ctx->ev[3]));
-    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[3], ctx->ev[2]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[3], ctx->ev[4]));
+    PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_overflow, ctx->ev[4], ctx->ev[2]));
     if (stats) return par_get_stats(ctx, stats);
     return PAR_OK;
 }

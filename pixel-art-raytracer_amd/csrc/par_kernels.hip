@@ -1106,12 +1106,17 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     // frames in flight / one): y=1: 38.6 / 72.8 us, y=2: 39.9 / 66.0, y=4: 41.1 / 64.8, y=8: 44.3 / 64.9.
     const int parts = bound >= 2048 ? 2 : (bound >= 512 ? 4 : 8);
     const int cost_per_part = bound >= 2048 ? 100 : (bound >= 512 ? 50 : 25);
-    if (!a.dense) {
-        hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0,
-                           stream, g, a, cost_per_part);
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
+    if (a.dense) return hipSuccess;
+    hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0, stream, g,
+                       a, cost_per_part);
+    return hipGetLastError();
+}
+
+hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                                      hipStream_t stream) {
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
+    if (bound <= 0) return hipSuccess;
     // overflowed columns are the exception: a small strided grid (up to 8 workgroups share a column)
     const int64_t oblocks = a.dense ? (bound < 1024 ? bound : 1024) : (bound < 32 ? bound : 32);
     hipLaunchKernelGGL(render_overflow_kernel, dim3((unsigned)oblocks, 8u), dim3(PAR_WAVE_NW * 64), 0, stream, g, a);

@@ -55,7 +55,7 @@ def test_update_aabbs_between_frames(par, oracle, sprite, T):
             assert_planes_equal(out, oracle.render(params, aabbs, sprite, light), ALL, f"frame {f}")
 
 
-def test_overflowing_columns_take_the_generic_kernel(par, oracle, sprite, T):
+def test_overflowing_columns_take_the_overflow_kernel(par, oracle, sprite, T):
     # hundreds of boxes stacked into a few columns: more slot records / occluders than a column record holds
     w, h, l = 480, 320, 320
     params = T.default_params(w, h, l)
@@ -71,6 +71,7 @@ def test_overflowing_columns_take_the_generic_kernel(par, oracle, sprite, T):
             r.set_scene(aabbs, sprite, light)
             fast = r.render(("fb", "palidx", "brightness", "gbuf"))
             assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"overflow {lpos}")
+            assert r.stats().overflow_columns > 0, "the scene is meant to overflow some column records"
             assert_planes_equal(r.render(ALL), exp, ALL, f"overflow dense {lpos}")
 
 
@@ -173,9 +174,10 @@ def test_host_demo_binary(par, oracle, T, tmp_path):
             np.array_equal(rgb[:, 2], fb["blue"]), f"frame {f}"
 
 
-def test_generic_kernel_on_every_tile(tmp_path):
-    """PAR_FORCE_GENERIC=1 sends every tile through the self-contained generic kernel (in-kernel group walks): the
-    path overflowed columns take. Run in a fresh process (the switch is read once) and compare with the oracle."""
+def test_overflow_kernel_on_every_column(tmp_path):
+    """PAR_FORCE_GENERIC=1 sends every column through render_overflow_kernel (primary pass straight from the hash,
+    shadow walks in-kernel): the path overflowed columns take. Run in a fresh process (the switch is read once) and
+    compare with the oracle."""
     import os
     import subprocess
     import sys

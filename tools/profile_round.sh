@@ -14,3 +14,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python3 tools/frames.py synthetic 40 > $out/pmc_$c.log 2> $out/rocprof_pmc_$c.err
 done
 find $out -name "*stats*.csv" | head; find $out -name "*counter*" | head
+python3 tools/hbm_traffic.py $out > $out/hbm_traffic.json
