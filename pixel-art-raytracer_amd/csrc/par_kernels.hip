@@ -594,17 +594,27 @@ __device__ __forceinline__ void fill_body(const par_render_args& a, uint32_t out
             for (int h = 0; h < 2; h++) {
                 const int x = x0 + h * 256 + lane * 4;
                 if (x < W) {
-                    *reinterpret_cast<uint4*>(fb + rowbase + x) = make_uint4(out_rgba, out_rgba, out_rgba, out_rgba);
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 v = {out_rgba, out_rgba, out_rgba, out_rgba};
+                    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(fb + rowbase + x));
                 }
             }
         }
         if (a.out.palidx) {
             const int x = x0 + lane * 8;
-            if (x < W) *reinterpret_cast<uint2*>(a.out.palidx + rowbase + x) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (x < W) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 v = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(a.out.palidx + rowbase + x));
+            }
         }
         if (a.out.lit) {  // the background ray of column x, traced once by bgline_kernel
             const int x = x0 + lane * 8;
-            if (x < W) *reinterpret_cast<uint2*>(a.out.lit + rowbase + x) = *reinterpret_cast<const uint2*>(bglit + x);
+            if (x < W) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_nontemporal_store(*reinterpret_cast<const u32x2*>(bglit + x),
+                                            reinterpret_cast<u32x2*>(a.out.lit + rowbase + x));
+            }
         }
     }
 }
@@ -874,8 +884,8 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
     } else if (valid && hit) {  // (uncovered pixels keep what the fill wrote)
         const size_t o = (size_t)(row - a.row_begin) * W + col;
-        if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
-        if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
+        if (a.out.fb) __builtin_nontemporal_store(color_scale(rgba, bright), reinterpret_cast<uint32_t*>(a.out.fb) + o);
+        if (a.out.palidx) __builtin_nontemporal_store((uint8_t)pal_index, a.out.palidx + o);
         if (a.out.brightness) a.out.brightness[o] = bright;
         if (a.out.lit) a.out.lit[o] = lit_px ? 1 : 0;
         if (a.out.gbuf) {
