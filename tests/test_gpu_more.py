@@ -62,7 +62,10 @@ def test_overflowing_columns_take_the_overflow_kernel(par, oracle, sprite, T):
     rng = np.random.default_rng(2)
     rows = [(int(rng.integers(200, 260)), int(rng.integers(0, 40)), int(z), 20, 20, 20)
             for z in rng.integers(0, 300, 500)]
-    rows += [(i * 20, 0, j * 20, 20, 20, 20) for i in range(24) for j in range(16)]
+    rows += [(i * 20, 0, j * 20, 20, 20, 20) for i in range(24) for j in range(16) if not 4 <= i < 8]
+    # seven boxes in each of the eight z-bins of ONE screen column (y + z constant keeps them on the same rows):
+    # 56 slot records where a column record holds 48
+    rows += [(100 + k, 260 - 40 * b, 40 * b + 10, 20, 20, 20) for b in range(8) for k in range(7)]
     aabbs = T.make_aabbs(rows)
     for lpos in [(300, 160, 80), (230, 60, 10)]:
         light = T.make_light(*lpos)
@@ -73,6 +76,24 @@ def test_overflowing_columns_take_the_overflow_kernel(par, oracle, sprite, T):
             assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"overflow {lpos}")
             assert r.stats().overflow_columns > 0, "the scene is meant to overflow some column records"
             assert_planes_equal(r.render(ALL), exp, ALL, f"overflow dense {lpos}")
+
+
+def test_long_shadow_walks_overflow_the_stage(par, oracle, sprite, T):
+    # a row of full bins between the primitives and the light: the walk from the far end collects more occluder
+    # records (11 bins x 7) than a start bin's list (64) or the in-kernel stage holds, so those columns overflow
+    # and their shadow rays end in trace_hash_for_light as written, per lane
+    w, h, l = 480, 320, 320
+    params = T.default_params(w, h, l)
+    rows = [(40 * bx + 2 * k, 100, 100, 20, 20, 20) for bx in range(12) for k in range(7)]
+    rows += [(i * 20, 0, j * 20, 20, 20, 20) for i in range(24) for j in range(16)]
+    aabbs = T.make_aabbs(rows)
+    for lpos in [(470, 110, 110), (475, 118, 102), (5, 110, 110)]:
+        light = T.make_light(*lpos)
+        exp = oracle.render(params, aabbs, sprite, light)
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            assert_planes_equal(r.render(ALL), exp, ALL, f"long walk {lpos}")
+            assert r.stats().overflow_columns > 0, "the walks are meant to overflow"
 
 
 def test_shadow_rays_from_unoccupied_bins(par, oracle, T):
