@@ -57,7 +57,8 @@ struct par_colrec {
     par_slot walk[PAR_COL_WALK];
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
-static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry");
+static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");
+static_assert((PAR_COL_NB & (PAR_COL_NB - 1)) == 0 && PAR_COL_NB <= 64, "one occupied bin per lane");
 constexpr int PAR_COL_WAVES = 2;         // wavefronts per columns_kernel workgroup (one shadow walk each at a time)
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world

@@ -710,10 +710,30 @@ struct WaveScratch {  // per wavefront: what wave_walk needs
     par_slot stage[PAR_BIN_WALK];
 };
 
+// A column record's wave-uniform tables, one element per lane (loaded once per wavefront and column): an element is
+// then read with v_readlane instead of a dependent load per use.
+struct ColumnRegs {
+    uint4 ent;     // lane e: entries[e]
+    int32_t ebz;   // lane e: ebz[e]
+    uint2 nb;      // lane n: nb[n]
+};
+
+__device__ __forceinline__ par_slot slot_of_lane(const uint4& v, int e) {
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)v.x, e), d1 = (uint32_t)__builtin_amdgcn_readlane((int)v.y, e);
+    const uint32_t d2 = (uint32_t)__builtin_amdgcn_readlane((int)v.z, e);
+    par_slot r;
+    r.px = (int16_t)(d0 & 0xFFFF); r.py = (int16_t)(d0 >> 16);
+    r.pz = (int16_t)(d1 & 0xFFFF); r.ex = (int16_t)(d1 >> 16);
+    r.ey = (int16_t)(d2 & 0xFFFF); r.ez = (int16_t)(d2 >> 16);
+    r.entity = __builtin_amdgcn_readlane((int)v.w, e);
+    return r;
+}
+
 template <bool GENERIC>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
-                                             const par_frame_dyn& dyn, int n_entries, int n_nb, int bx, int by,
-                                             int own, int col, int row, bool valid, int lane, WaveScratch* ws) {
+                                             const ColumnRegs& cr, const par_frame_dyn& dyn, int n_entries, int n_nb,
+                                             int bx, int by, int own, int col, int row, bool valid, int lane,
+                                             WaveScratch* ws) {
     const int W = a.W, H = a.H;
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
@@ -761,8 +781,8 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         };
         if (!GENERIC) {  // the record's entries as one flat list
             for (int e = 0; e < n_entries; e++) {
-                const int bz = rec_.ebz[e];
-                const par_slot rec = rec_.entries[e];
+                const int bz = __builtin_amdgcn_readlane(cr.ebz, e);
+                const par_slot rec = slot_of_lane(cr.ent, e);
                 if (bz != cur_bz) next_bin(bz);
                 // a lane whose pixel an earlier entry owns has nothing to do in this pass
                 if (first_cover < own) done = true;  // (never in tile mode: own = -1)
@@ -820,19 +840,30 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         sz = div_bin(wz, a.magic_b);                                       // alt:727
         ox = (int)(int16_t)col; oy = (int)(int16_t)p_y; oz = (int)(int16_t)p_z;  // alt:720-722
         // shadow ray, alt:738-742: columns_kernel has walked from every occupied bin of the column
-        int wi = -1;
+        int woff = 0, wcnt = -1;
         if (!GENERIC && sy == by) {
             for (int n = 0; n < n_nb; n++) {
-                if (rec_.nb[n].bz == sz) wi = n;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cr.nb.x, n);
+                const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.nb.y, n);
+                if ((int)(int16_t)(d0 & 0xFFFF) == sz) {
+                    woff = (int)(d1 & 0xFFFF);
+                    wcnt = (int)(d1 >> 16);
+                }
             }
         }
-        if (wi >= 0) {
-            const int woff = rec_.nb[wi].woff, wcnt = rec_.nb[wi].wcnt;
-            for (int r = 0; r < wcnt; r++) {
-                const par_slot rec = rec_.walk[woff + r];
-                if (rec.entity != p_entity && slab_hit(rec, ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
-                    lit = false;
-                    break;
+        if (wcnt >= 0) {
+            // four records per step: their loads are in flight together
+            const par_slot* wl = rec_.walk + woff;
+            for (int r0 = 0; r0 < wcnt && lit; r0 += 4) {
+                par_slot w[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) w[u] = wl[min(r0 + u, wcnt - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (r0 + u < wcnt && w[u].entity != p_entity &&
+                        slab_hit(w[u], ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
+                        lit = false;
+                    }
                 }
             }
         } else if (GENERIC) {
@@ -927,6 +958,15 @@ __device__ __forceinline__ void render_column(const par_grid_dev& g, const par_r
     const int bx = rec_.bx, by = rec_.by;
     const bool tile_mode = GENERIC || rec_.tile_mode != 0;
     const uint64_t dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
+    ColumnRegs cr;
+    cr.ent = make_uint4(0, 0, 0, 0);
+    cr.ebz = 0;
+    cr.nb = make_uint2(0, 0);
+    if (!GENERIC) {
+        cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
+        cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
+        cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
+    }
     if (!GENERIC && rec_.overflow) return;  // render_overflow_kernel's
     // a column's chunks are shared by as many workgroups as its work is worth (the others of its row leave at once)
     const int col_parts =
@@ -950,7 +990,7 @@ __device__ __forceinline__ void render_column(const par_grid_dev& g, const par_r
         if (tile_mode) {
             rx0 = c0; rw = tw; ry0 = rows_lo; rh = rows_hi - rows_lo;
         } else {
-            const par_slot r = rec_.entries[q];
+            const par_slot r = slot_of_lane(cr.ent, q);
             rx0 = max((int)r.px, c0);
             rw = min(r.px + r.ex, c0 + tw) - rx0;
             // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
@@ -975,7 +1015,7 @@ __device__ __forceinline__ void render_column(const par_grid_dev& g, const par_r
             const int pidx = c * 64 + lane;
             const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
             const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
-            render_chunk<GENERIC>(g, a, rec_, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane,
+            render_chunk<GENERIC>(g, a, rec_, cr, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane,
                                   ws ? ws + wave : nullptr);
         }
     }
