@@ -731,9 +731,9 @@ __device__ __forceinline__ par_slot slot_of_lane(const uint4& v, int e) {
 
 template <bool GENERIC>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
-                                             const ColumnRegs& cr, const par_frame_dyn& dyn, int n_entries, int n_nb,
-                                             int bx, int by, int own, int col, int row, bool valid, int lane,
-                                             WaveScratch* ws) {
+                                             const ColumnRegs& cr, uint64_t dup, const par_frame_dyn& dyn,
+                                             int n_entries, int n_nb, int bx, int by, int own, int col, int row,
+                                             bool valid, int lane, WaveScratch* ws) {
     const int W = a.W, H = a.H;
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
@@ -782,8 +782,11 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         if (!GENERIC) {  // the record's entries as one flat list
             for (int e = 0; e < n_entries; e++) {
                 const int bz = __builtin_amdgcn_readlane(cr.ebz, e);
-                const par_slot rec = slot_of_lane(cr.ent, e);
                 if (bz != cur_bz) next_bin(bz);
+                // An entry that repeats an earlier entry's entity (the same AABB in another bin) gives the same
+                // depth: it can neither improve `closest` (strict compare, alt:344) nor be the first to cover.
+                if ((dup >> e) & 1) continue;
+                const par_slot rec = slot_of_lane(cr.ent, e);
                 // a lane whose pixel an earlier entry owns has nothing to do in this pass
                 if (first_cover < own) done = true;  // (never in tile mode: own = -1)
                 if (__all(done)) break;  // wavefront early-out
@@ -1015,7 +1018,7 @@ __device__ __forceinline__ void render_column(const par_grid_dev& g, const par_r
             const int pidx = c * 64 + lane;
             const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
             const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
-            render_chunk<GENERIC>(g, a, rec_, cr, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane,
+            render_chunk<GENERIC>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane,
                                   ws ? ws + wave : nullptr);
         }
     }
