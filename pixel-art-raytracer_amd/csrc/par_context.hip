@@ -254,31 +254,29 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
     }
     if (ev) PAR_HIP(hipEventRecord(ev[0], stream));
-    PAR_HIP(par_launch_bin_insert(ctx->grid, b, stream));
+    // The background fill depends on nothing earlier in the frame and the render kernels come after all of it: when
+    // it is the plain streaming one it rides along with the first three launches (timed runs keep all kernels apart
+    // so that the event pairs bracket single ones).
+    par_fill_plan plan;
+    const bool ride = !ev && par_plan_fill(r, &plan);
+    PAR_HIP(par_launch_bin_insert(ctx->grid, b, &r, ride ? &plan : nullptr, stream));
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
     // what par_graph_stage accepts (graph_pair_bound); beyond it the caller captures again.
     const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : ctx->total_pairs;
-    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, stream));
+    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, &r, ride ? &plan : nullptr, stream));
     // occupied columns <= the columns the entities reach one by one (<= their (entity, bin) pairs)
     const int64_t col_bound = graph_mode ? pair_bound : ctx->total_cols;
-    // The background fill depends on nothing earlier in the frame: it shares the column kernel's launch when it is
-    // the plain streaming one (timed runs keep all kernels apart so that the event pairs bracket single ones).
-    bool merged = false;
-    if (!ev) {
-        const hipError_t e = par_launch_columns_fill(ctx->grid, r, col_bound, stream);
-        if (e == hipSuccess) {
-            merged = true;
-        } else if (e != hipErrorNotSupported) {
-            return hip_fail(ctx, e, "par_launch_columns_fill");
-        }
+    if (ride) {
+        PAR_HIP(par_launch_columns_fill(ctx->grid, r, col_bound, plan, stream));
+    } else {
+        PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
     }
-    if (!merged) PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[1], stream));
     // Otherwise the fill follows on the same stream. (Forking it onto a second stream beside the build was measured
     // slower, alone and with several frames in flight: the cross-stream events cost more than the overlap gains.)
     // It follows the column kernels because, when background rays are traced, it copies their results into the lit
     // plane.
-    if (!merged) PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    if (!ride) PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[4], stream));

@@ -133,15 +133,27 @@ constexpr int PAR_WAVE_NW = 4;          // wavefronts per render_wave_kernel wor
 constexpr int PAR_WAVE_CHUNK_COST = 6;  // work of a 64-pixel chunk ~ entries tested + this (shading, shadow, stores)
 enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_TOTAL = 8 };
 
+// The background fill split over the frame's first three launches: 512-pixel chunks [cut[i], cut[i+1]) go with
+// launch i (hash insert, hash resolve, column records).
+struct par_fill_plan {
+    uint32_t out_rgba;  // Color{127,127,127,0} * ambient
+    int32_t cut[4];
+};
+
 // Launchers (par_kernels.hip). All asynchronous on `stream`.
-hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream);
-hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, hipStream_t stream);
+// True when the fill can ride along with the first three launches (else: par_launch_fill on its own).
+bool par_plan_fill(const par_render_args& a, par_fill_plan* plan);
+// `fill` (nullable, with the render args `fa`): this launch also carries its share of the fill.
+hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, const par_render_args* fa,
+                                 const par_fill_plan* fill, hipStream_t stream);
+hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound,
+                                  const par_render_args* fa, const par_fill_plan* fill, hipStream_t stream);
 // Per occupied column: compact slot list + the shadow walks of its bins (+ the background walks when a.trace_bg);
 // then, when a.trace_bg, the background rays themselves (one per x).
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, hipStream_t stream);
-// Column records + background fill in one launch when possible (else hipErrorNotSupported, nothing launched).
+// Column records + the last share of the fill in one launch.
 hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
-                                   hipStream_t stream);
+                                   const par_fill_plan& fill, hipStream_t stream);
 // Background for every pixel of the row range; the render kernel then overwrites the pixels primitives cover.
 // Independent of the hash.
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);

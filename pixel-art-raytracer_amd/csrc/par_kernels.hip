@@ -12,8 +12,10 @@
 //   render_wave_kernel  trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect alt:40-83,
 //                       Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column records,
 //                       64 pixels per wavefront, no workgroup cooperation
-//   render_tiles_kernel the same, self-contained (walks in-kernel): the columns that overflow a record
-//                       (PAR_FORCE_GENERIC=1: every tile)
+//   render_overflow_kernel  the columns that overflow a record, straight from the hash, walks in-kernel
+//                       (PAR_FORCE_GENERIC=1: every column)
+// The background fill has no launch of its own: the first three launches each carry a share of it (extra
+// workgroups running fill_body), sized so that it rides along in their shadow.
 //
 // Float discipline: compiled with -ffp-contract=off; divisions are hipcc's default correctly-rounded fp32
 // division; min/max are the ?: forms of std::min/std::max so NaN handling follows the reference (first argument
@@ -143,8 +145,8 @@ __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin
     bin_insert_body<ENT>(g, a, (int)blockIdx.x, (int)gridDim.x);
 }
 
-__global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bin_args a) {
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bin_resolve_body(const par_grid_dev& g, const par_bin_args& a, int block) {
+    const int tid = block * blockDim.x + threadIdx.x;
     const int s = a.set;
     // insert (the previous kernel) has consumed the other set's counter: free it for the next frame's inserts
     if (tid == 0) g.node_counter[s ^ 1] = 0;
@@ -199,6 +201,10 @@ __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bi
             g.col_list[base + __popcll(m & ((1ull << lane) - 1ull))] = col;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bin_args a) {
+    bin_resolve_body(g, a, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -575,17 +581,18 @@ __global__ __launch_bounds__(256) void bgline_kernel(par_grid_dev g, par_render_
 // Requires W % 8 == 0 and 16-byte aligned planes; otherwise fill_generic_kernel runs.
 // ------------------------------------------------------------------------------------------------------------
 
+// `part` = {first chunk, end chunk} of this launch's share, or {0, -1} for all of them.
 __device__ __forceinline__ void fill_body(const par_render_args& a, uint32_t out_rgba, const uint8_t* bglit, int block,
-                                          int n_blocks) {
+                                          int n_blocks, int2 part) {
     const int W = a.W;
     const int rows = a.row_end - a.row_begin;
     const int cpr = (W + 511) >> 9;  // 512-pixel chunks per row
-    const int n_chunks = rows * cpr;
+    const int n_chunks = part.y < 0 ? rows * cpr : part.y;
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     uint32_t* fb = reinterpret_cast<uint32_t*>(a.out.fb);
     // one chunk per wavefront per iteration; the chunk index is wave-uniform (kept in scalar registers)
-    for (int c = __builtin_amdgcn_readfirstlane(block * wpb + ((int)threadIdx.x >> 6)); c < n_chunks;
+    for (int c = __builtin_amdgcn_readfirstlane(part.x + block * wpb + ((int)threadIdx.x >> 6)); c < n_chunks;
          c += n_blocks * wpb) {
         const int y = c / cpr, x0 = (c - y * cpr) << 9;
         const size_t rowbase = (size_t)y * W;
@@ -620,19 +627,39 @@ __device__ __forceinline__ void fill_body(const par_render_args& a, uint32_t out
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t out_rgba, const uint8_t* bglit) {
-    fill_body(a, out_rgba, bglit, (int)blockIdx.x, (int)gridDim.x);
+    fill_body(a, out_rgba, bglit, (int)blockIdx.x, (int)gridDim.x, make_int2(0, -1));
 }
 
 // The background fill does not depend on the hash, and it takes about as long as the column records of a
 // 16 Mpixel frame: one launch for both (the first `n_col` workgroups build column records, the others fill), so the
 // fill costs the frame's launch chain neither a link nor its own duration.
 __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_fill_kernel(par_grid_dev g, par_render_args a,
-                                                                          uint32_t out_rgba, int n_col) {
+                                                                          uint32_t out_rgba, int n_col, int2 part) {
     __shared__ ColShared sm;
     if ((int)blockIdx.x < n_col) {
         columns_body(g, a, sm, (int)blockIdx.x, n_col);
     } else {
-        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col, (int)gridDim.x - n_col);
+        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col, (int)gridDim.x - n_col, part);
+    }
+}
+
+// The same for the two short kernels of the hash build: each carries a smaller share of the fill.
+template <int ENT>
+__global__ __launch_bounds__(256) void insert_fill_kernel(par_grid_dev g, par_bin_args b, par_render_args a,
+                                                           uint32_t out_rgba, int n_insert, int2 part) {
+    if ((int)blockIdx.x < n_insert) {
+        bin_insert_body<ENT>(g, b, (int)blockIdx.x, n_insert);
+    } else {
+        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_insert, (int)gridDim.x - n_insert, part);
+    }
+}
+
+__global__ __launch_bounds__(256) void resolve_fill_kernel(par_grid_dev g, par_bin_args b, par_render_args a,
+                                                            uint32_t out_rgba, int n_resolve, int2 part) {
+    if ((int)blockIdx.x < n_resolve) {
+        bin_resolve_body(g, b, (int)blockIdx.x);
+    } else {
+        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_resolve, (int)gridDim.x - n_resolve, part);
     }
 }
 
@@ -1052,7 +1079,37 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_overflow_kernel(par_g
 
 }  // namespace
 
-hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, hipStream_t stream) {
+// The fill rides along with the first three launches when it needs only the streaming kernel (frame and
+// palette-index planes, aligned, no lit plane): shares of its 512-pixel chunks in proportion to what those launches
+// take anyway (insert 5.6 us, resolve 5.6 us, column records 17.6 us at 4096^2 / 1024 primitives; the fill writes
+// about 5 MB per microsecond). Returns false when the fill has to be launched on its own (par_launch_fill).
+bool par_plan_fill(const par_render_args& a, par_fill_plan* plan) {
+    const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
+    const bool pal_fast = !a.out.palidx || ((a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0));
+    if (a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) return false;
+    const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);  // Color{127,127,127,0} * ambient
+    plan->out_rgba = ch | (ch << 8) | (ch << 16);
+    const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
+    if (chunks > 0x7FFFFFFF) return false;
+    plan->cut[0] = 0;
+    // (Measured at 4096^2, three frames in flight: 0/0/100 % 36.5 us per frame, 10/10/80 35.7, 20/20/60 34.1,
+    // 25/25/50 34.5, 33/33/33 34.0.)
+    plan->cut[1] = (int)(chunks / 5);
+    plan->cut[2] = (int)(chunks * 2 / 5);
+    plan->cut[3] = (int)chunks;
+    return true;
+}
+
+// fill workgroups (of `waves` wavefronts) for the chunks [cut[i], cut[i+1]): one chunk per wavefront and iteration
+static int64_t fill_blocks(const par_fill_plan& p, int i, int waves, int64_t cap) {
+    const int64_t chunks = p.cut[i + 1] - p.cut[i];
+    int64_t n = (chunks + waves - 1) / waves;
+    if (n > cap) n = cap;
+    return n < 0 ? 0 : n;
+}
+
+hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, const par_render_args* fa,
+                                 const par_fill_plan* fill, hipStream_t stream) {
     // ENT entities per wavefront; the wipe of the previous frame's nodes is a grid-stride loop over <= capacity
     const bool small = a.n <= 16384;
     int64_t work = (int64_t)a.n * (small ? 4 : 1);  // threads = waves * 64 = n / ENT * 64
@@ -1060,7 +1117,17 @@ hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, h
     int64_t blocks = (work + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
-    if (small) {
+    if (fill) {
+        const int64_t nf = fill_blocks(*fill, 0, 4, 256);
+        const int2 part = make_int2(fill->cut[0], fill->cut[1]);
+        if (small) {
+            hipLaunchKernelGGL(insert_fill_kernel<16>, dim3((unsigned)(blocks + nf)), dim3(256), 0, stream, g, a, *fa,
+                               fill->out_rgba, (int)blocks, part);
+        } else {
+            hipLaunchKernelGGL(insert_fill_kernel<64>, dim3((unsigned)(blocks + nf)), dim3(256), 0, stream, g, a, *fa,
+                               fill->out_rgba, (int)blocks, part);
+        }
+    } else if (small) {
         hipLaunchKernelGGL(bin_insert_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
     } else {
         hipLaunchKernelGGL(bin_insert_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
@@ -1069,10 +1136,16 @@ hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, h
 }
 
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound,
-                                  hipStream_t stream) {
+                                  const par_render_args* fa, const par_fill_plan* fill, hipStream_t stream) {
     int64_t blocks = (pair_bound + 255) / 256;
     if (blocks < 1) blocks = 1;  // block 0 always runs: it resets the other set's node counter
-    hipLaunchKernelGGL(bin_resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    if (fill) {
+        const int64_t nf = fill_blocks(*fill, 1, 4, 256);
+        hipLaunchKernelGGL(resolve_fill_kernel, dim3((unsigned)(blocks + nf)), dim3(256), 0, stream, g, a, *fa,
+                           fill->out_rgba, (int)blocks, make_int2(fill->cut[1], fill->cut[2]));
+    } else {
+        hipLaunchKernelGGL(bin_resolve_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
+    }
     return hipGetLastError();
 }
 
@@ -1090,28 +1163,18 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
     return hipGetLastError();
 }
 
-// Column records + fill in one launch when the fill needs only the streaming kernel (frame and palette-index planes,
-// aligned, no lit plane). Returns hipErrorNotSupported (nothing launched) otherwise: the caller launches them apart.
+// Column records + the last share of the fill in one launch.
 hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
-                                   hipStream_t stream) {
-    const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
-    const bool pal_fast = !a.out.palidx || ((a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0));
-    if (a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) {
-        return hipErrorNotSupported;
-    }
+                                   const par_fill_plan& fill, hipStream_t stream) {
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     int64_t n_col = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (n_col < 0) n_col = 0;
-    const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);  // Color{127,127,127,0} * ambient
-    const uint32_t out_rgba = ch | (ch << 8) | (ch << 16);
-    const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
-    int64_t n_fill = (chunks + PAR_COL_WAVES - 1) / PAR_COL_WAVES;
-    // Measured at 4096^2 (three frames in flight / one): 1024 fill workgroups 49.7 / 84.1 us, 256: 52.8 / 83.9,
-    // 4096: 51.4 / 84.0; fill and column kernels apart: 51.7 / 92.2.
-    if (n_fill > 1024) n_fill = 1024;
-    if (n_fill < 1) n_fill = 1;
+    // Measured at 4096^2 with the whole fill in this launch (three frames in flight / one): 1024 fill workgroups
+    // 49.7 / 84.1 us, 256: 52.8 / 83.9, 4096: 51.4 / 84.0; fill and column kernels apart: 51.7 / 92.2.
+    int64_t n_fill = fill_blocks(fill, 2, PAR_COL_WAVES, 1024);
+    if (n_col + n_fill <= 0) return hipSuccess;
     hipLaunchKernelGGL(columns_fill_kernel, dim3((unsigned)(n_col + n_fill)), dim3(PAR_COL_WAVES * 64), 0, stream, g,
-                       a, out_rgba, (int)n_col);
+                       a, fill.out_rgba, (int)n_col, make_int2(fill.cut[2], fill.cut[3]));
     return hipGetLastError();
 }
 
