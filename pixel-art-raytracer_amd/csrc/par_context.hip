@@ -259,15 +259,17 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // so that the event pairs bracket single ones).
     par_fill_plan plan;
     const bool ride = !ev && par_plan_fill(r, &plan);
-    PAR_HIP(par_launch_bin_insert(ctx->grid, b, &r, ride ? &plan : nullptr, stream));
+    par_render_args rf = r;  // what rides along: the frame and palette-index planes
+    rf.out.lit = nullptr;
+    PAR_HIP(par_launch_bin_insert(ctx->grid, b, &rf, ride ? &plan : nullptr, stream));
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
     // what par_graph_stage accepts (graph_pair_bound); beyond it the caller captures again.
     const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : ctx->total_pairs;
-    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, &r, ride ? &plan : nullptr, stream));
+    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, &rf, ride ? &plan : nullptr, stream));
     // occupied columns <= the columns the entities reach one by one (<= their (entity, bin) pairs)
     const int64_t col_bound = graph_mode ? pair_bound : ctx->total_cols;
     if (ride) {
-        PAR_HIP(par_launch_columns_fill(ctx->grid, r, col_bound, plan, stream));
+        PAR_HIP(par_launch_columns_fill(ctx->grid, rf, col_bound, plan, stream));
     } else {
         PAR_HIP(par_launch_columns(ctx->grid, r, col_bound, stream));
     }
@@ -276,7 +278,14 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // slower, alone and with several frames in flight: the cross-stream events cost more than the overlap gains.)
     // It follows the column kernels because, when background rays are traced, it copies their results into the lit
     // plane.
-    if (!ride) PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    if (!ride) {
+        PAR_HIP(par_launch_fill(ctx->grid, r, stream));
+    } else if (r.out.lit) {  // the lit plane of the background: after the background rays
+        par_render_args rl = r;
+        rl.out.fb = nullptr;
+        rl.out.palidx = nullptr;
+        PAR_HIP(par_launch_fill(ctx->grid, rl, stream));
+    }
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[4], stream));

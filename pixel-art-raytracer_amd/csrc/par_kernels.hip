@@ -1080,13 +1080,14 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_overflow_kernel(par_g
 }  // namespace
 
 // The fill rides along with the first three launches when it needs only the streaming kernel (frame and
-// palette-index planes, aligned, no lit plane): shares of its 512-pixel chunks in proportion to what those launches
-// take anyway (insert 5.6 us, resolve 5.6 us, column records 17.6 us at 4096^2 / 1024 primitives; the fill writes
-// about 5 MB per microsecond). Returns false when the fill has to be launched on its own (par_launch_fill).
+// palette-index planes, aligned): shares of its 512-pixel chunks in proportion to what those launches take anyway
+// (insert 5.6 us, resolve 5.6 us, column records 17.6 us at 4096^2 / 1024 primitives; the fill writes about 5 MB per
+// microsecond). A lit plane is filled afterwards (it needs the background rays, bgline_kernel). Returns false when
+// the whole fill has to be launched on its own (par_launch_fill).
 bool par_plan_fill(const par_render_args& a, par_fill_plan* plan) {
     const bool fb_fast = a.out.fb && (a.W % 8 == 0) && ((uintptr_t)a.out.fb % 16 == 0);
     const bool pal_fast = !a.out.palidx || ((a.W % 8 == 0) && ((uintptr_t)a.out.palidx % 8 == 0));
-    if (a.trace_bg || !fb_fast || !pal_fast || a.out.brightness || a.out.gbuf || a.out.lit) return false;
+    if (!fb_fast || !pal_fast || a.out.brightness || a.out.gbuf) return false;
     const uint32_t ch = (uint32_t)(uint8_t)((float)a.background * a.ambient);  // Color{127,127,127,0} * ambient
     plan->out_rgba = ch | (ch << 8) | (ch << 16);
     const int64_t chunks = (int64_t)(a.row_end - a.row_begin) * ((a.W + 511) / 512);
@@ -1169,12 +1170,16 @@ hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args&
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     int64_t n_col = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (n_col < 0) n_col = 0;
+    if (a.trace_bg) n_col += g.gx;  // the background walks
     // Measured at 4096^2 with the whole fill in this launch (three frames in flight / one): 1024 fill workgroups
     // 49.7 / 84.1 us, 256: 52.8 / 83.9, 4096: 51.4 / 84.0; fill and column kernels apart: 51.7 / 92.2.
     int64_t n_fill = fill_blocks(fill, 2, PAR_COL_WAVES, 1024);
     if (n_col + n_fill <= 0) return hipSuccess;
     hipLaunchKernelGGL(columns_fill_kernel, dim3((unsigned)(n_col + n_fill)), dim3(PAR_COL_WAVES * 64), 0, stream, g,
                        a, fill.out_rgba, (int)n_col, make_int2(fill.cut[2], fill.cut[3]));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !a.trace_bg) return e;
+    hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
     return hipGetLastError();
 }
 
