@@ -1101,7 +1101,12 @@ bool par_plan_fill(const par_render_args& a, par_fill_plan* plan) {
     return true;
 }
 
-// fill workgroups (of `waves` wavefronts) for the chunks [cut[i], cut[i+1]): one chunk per wavefront and iteration
+// fill workgroups (of `waves` wavefronts) for the chunks [cut[i], cut[i+1]): one chunk per wavefront and iteration.
+// Few wavefronts are enough to write at full rate, and every resident fill wavefront is a slot another frame's
+// kernels cannot use. Measured at 4096^2 (three frames in flight / one), workgroups in the insert and resolve
+// launches / in the column launch: 256 / 1024: 34.6 / 59.5 us, 128 / 512: 32.7 / 58.3, 64 / 256: 31.5 / 58.1,
+// 32 / 128: 33.1 / 66.8, 16 / 64: 40.7 / 94.7.
+constexpr int PAR_FILL_RIDE_WGS = 64;
 static int64_t fill_blocks(const par_fill_plan& p, int i, int waves, int64_t cap) {
     const int64_t chunks = p.cut[i + 1] - p.cut[i];
     int64_t n = (chunks + waves - 1) / waves;
@@ -1119,7 +1124,7 @@ hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, c
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     if (fill) {
-        const int64_t nf = fill_blocks(*fill, 0, 4, 256);
+        const int64_t nf = fill_blocks(*fill, 0, 4, PAR_FILL_RIDE_WGS);
         const int2 part = make_int2(fill->cut[0], fill->cut[1]);
         if (small) {
             hipLaunchKernelGGL(insert_fill_kernel<16>, dim3((unsigned)(blocks + nf)), dim3(256), 0, stream, g, a, *fa,
@@ -1141,7 +1146,7 @@ hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, 
     int64_t blocks = (pair_bound + 255) / 256;
     if (blocks < 1) blocks = 1;  // block 0 always runs: it resets the other set's node counter
     if (fill) {
-        const int64_t nf = fill_blocks(*fill, 1, 4, 256);
+        const int64_t nf = fill_blocks(*fill, 1, 4, PAR_FILL_RIDE_WGS);
         hipLaunchKernelGGL(resolve_fill_kernel, dim3((unsigned)(blocks + nf)), dim3(256), 0, stream, g, a, *fa,
                            fill->out_rgba, (int)blocks, make_int2(fill->cut[1], fill->cut[2]));
     } else {
@@ -1171,9 +1176,7 @@ hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args&
     int64_t n_col = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (n_col < 0) n_col = 0;
     if (a.trace_bg) n_col += g.gx;  // the background walks
-    // Measured at 4096^2 with the whole fill in this launch (three frames in flight / one): 1024 fill workgroups
-    // 49.7 / 84.1 us, 256: 52.8 / 83.9, 4096: 51.4 / 84.0; fill and column kernels apart: 51.7 / 92.2.
-    int64_t n_fill = fill_blocks(fill, 2, PAR_COL_WAVES, 1024);
+    int64_t n_fill = fill_blocks(fill, 2, PAR_COL_WAVES, 4 * PAR_FILL_RIDE_WGS);
     if (n_col + n_fill <= 0) return hipSuccess;
     hipLaunchKernelGGL(columns_fill_kernel, dim3((unsigned)(n_col + n_fill)), dim3(PAR_COL_WAVES * 64), 0, stream, g,
                        a, fill.out_rgba, (int)n_col, make_int2(fill.cut[2], fill.cut[3]));
@@ -1224,7 +1227,7 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     if (bound <= 0) return hipSuccess;
     // gridDim.y workgroups per column (a column uses as many as its work is worth); few columns: more of them, and
     // finer parts, so that a small frame still spreads over the chip. Measured at 4096^2 / 1024 primitives (three
-    // frames in flight / one): y=1: 38.6 / 72.8 us, y=2: 39.9 / 66.0, y=4: 41.1 / 64.8, y=8: 44.3 / 64.9.
+    // frames in flight / one): y=1: 30.8 / 62.7 us, y=2: 31.6 / 58.2, y=3: 33.1 / 57.5, y=4: 33.1 / 57.6.
     const int parts = bound >= 2048 ? 2 : (bound >= 512 ? 4 : 8);
     const int cost_per_part = bound >= 2048 ? 100 : (bound >= 512 ? 50 : 25);
     if (a.dense) return hipSuccess;
