@@ -11,7 +11,7 @@ palette-index plane. Scene, sprites and output buffers are resident in HBM befor
 same frame is sharded by row block (rank r renders rows [H r/N, H (r+1)/N)) and the blocks are gathered to rank 0
 with one RCCL gather per frame (strong scaling: total work is fixed as N grows).
 
-Frames in flight: like a swap chain, `--inflight` (default 3) frames are in flight at once, each with its own context,
+Frames in flight: like a swap chain, `--inflight` (default 4) frames are in flight at once, each with its own context,
 stream and output buffers (pixel-art-raytracer_amd/pipeline.py); one frame alone is a chain of short latency-bound
 kernels that leaves most of the chip idle. `--inflight 1` gives the one-frame-at-a-time rate.
 
@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--inflight", type=int, default=3, help="frames in flight (contexts/streams/buffers)")
+    ap.add_argument("--inflight", type=int, default=4, help="frames in flight (contexts/streams/buffers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="tests: every rank uses GPU 0 (needs --backend gloo)")

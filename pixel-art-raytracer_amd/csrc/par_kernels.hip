@@ -1119,7 +1119,7 @@ hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, c
     // ENT entities per wavefront; the wipe of the previous frame's nodes is a grid-stride loop over <= capacity
     const bool small = a.n <= 16384;
     int64_t work = (int64_t)a.n * (small ? 4 : 1);  // threads = waves * 64 = n / ENT * 64
-    if (work < 65536) work = 65536;                 // (the wipe loop strides: any grid covers any node count)
+    if (work < 16384) work = 16384;                 // (the wipe loop strides: any grid covers any node count)
     int64_t blocks = (work + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;

@@ -24,7 +24,7 @@ class FrameSlot:
 
 
 class FramePipeline:
-    def __init__(self, params, aabbs, sprites, light, depth=3, device=0, rows=None, planes=("fb", "palidx"),
+    def __init__(self, params, aabbs, sprites, light, depth=4, device=0, rows=None, planes=("fb", "palidx"),
                  rows_alloc=None, sprite_ids=None):
         dev = torch.device("cuda", device)
         r0, r1 = rows or (0, params.height)
