@@ -510,3 +510,39 @@ def test_dense_floor_full_size(par, oracle, sprite, T):
         out = r.render(("fb", "palidx"))
         assert r.stats().bin_insertions > 65536
         assert out["fb"].tobytes() == exp["fb"].tobytes() and out["palidx"].tobytes() == exp["palidx"].tobytes()
+
+
+def test_random_sweep(par, oracle, sprite, T):
+    """Many small random configurations through the C ABI against the oracle: view sizes that are no multiple of the
+    bin size, bin sizes 8..64, lights inside, on the border of and outside the volume, clumped and spread primitives, odd extents,
+    row ranges, the riding fill (frame + palette index) and the standalone fill paths (every plane)."""
+    rng = np.random.default_rng(20260104)
+    for case in range(96):
+        b = int(rng.choice([8, 16, 20, 24, 32, 40, 40, 40, 48, 64]))
+        w = int(rng.integers(5, 90)) * 8 if case % 3 else int(rng.integers(40, 700))
+        h = int(rng.integers(40, 500))
+        l = int(rng.integers(40, 500))
+        n = int(rng.integers(1, 400))
+        params = T.default_params(w, h, l, b)
+        aabbs, light = par.scene_synthetic(n, w, h, l, int(rng.integers(1, 1 << 30)))
+        if case % 4 == 1:  # clump: many primitives in few bins (wrapping slot counters, long entry lists)
+            aabbs["px"] = (aabbs["px"] % max(2 * b, 40)).astype(aabbs["px"].dtype)
+            aabbs["pz"] = (aabbs["pz"] % max(3 * b, 60)).astype(aabbs["pz"].dtype)
+        if case % 6 == 3:  # any extents the sprite format allows (alt:330: ex <= 20, ey + ez <= 40), also 1 and 0 wide
+            aabbs["ex"] = rng.integers(0, 21, n).astype(aabbs["ex"].dtype)
+            aabbs["ey"] = rng.integers(0, 21, n).astype(aabbs["ey"].dtype)
+            aabbs["ez"] = (rng.integers(0, 21, n) % (41 - aabbs["ey"])).astype(aabbs["ez"].dtype)
+        if case % 5 == 2:  # light anywhere, also outside the volume and with negative coordinates
+            light = T.make_light(int(rng.integers(-100, w + 100)), int(rng.integers(-100, h + 100)),
+                                 int(rng.integers(-100, l + 100)))
+        exp = oracle.render(params, aabbs, sprite, light)
+        tag = f"case {case}: {w}x{h}x{l} bin {b}, {n} primitives, light {light}"
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            assert_planes_equal(r.render(("fb", "palidx")), exp, ("fb", "palidx"), tag + " (riding fill)")
+            assert_planes_equal(r.render(ALL), exp, ALL, tag + " (all planes)")
+            r0 = int(rng.integers(0, h - 1))
+            r1 = int(rng.integers(r0 + 1, h + 1))
+            part = r.render(("fb", "palidx", "lit"), rows=(r0, r1))
+            for k in ("fb", "palidx", "lit"):
+                assert part[k].tobytes() == exp[k][r0 * w:r1 * w].tobytes(), tag + f" rows {r0}..{r1} plane {k}"
