@@ -221,6 +221,25 @@ for (w, h, l, n, seed) in [(480, 320, 320, 300, 5), (512, 512, 512, 64, 12345), 
             out = r.render(planes)
             for k in planes:
                 assert out[k].tobytes() == exp[k].tobytes(), (w, h, k)
+rng = np.random.default_rng(7)
+for case in range(24):
+    b = int(rng.choice([8, 16, 20, 32, 40, 40, 64]))
+    w, h, l = int(rng.integers(5, 80)) * 8, int(rng.integers(40, 400)), int(rng.integers(40, 400))
+    n = int(rng.integers(1, 300))
+    params = T.default_params(w, h, l, b)
+    aabbs, light = par.scene_synthetic(n, w, h, l, int(rng.integers(1, 1 << 30)))
+    if case %% 3 == 1:
+        aabbs["px"] = (aabbs["px"] %% max(2 * b, 40)).astype(aabbs["px"].dtype)
+        aabbs["pz"] = (aabbs["pz"] %% max(3 * b, 60)).astype(aabbs["pz"].dtype)
+    if case %% 4 == 2:
+        light = T.make_light(int(rng.integers(-100, w + 100)), int(rng.integers(-100, h + 100)), int(rng.integers(-100, l + 100)))
+    exp = o.render(params, aabbs, sprite, light)
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        for planes in (("fb", "palidx"), ALL):
+            out = r.render(planes)
+            for k in planes:
+                assert out[k].tobytes() == exp[k].tobytes(), (case, w, h, l, b, n, k)
 aab = par.scene_graybox(); light = T.make_light(480, 160, 80); params = T.default_params()
 exp = o.render(params, aab, sprite, light)
 with par.Renderer(params) as r:
