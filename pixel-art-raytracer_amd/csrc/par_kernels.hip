@@ -1,21 +1,20 @@
 // par_kernels.hip — hand-written HIP kernels for gfx950 (MI355X / CDNA4).
 //
 // One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is five launches:
-//   bin_insert_kernel   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and deterministic
-//   bin_resolve_kernel  }   (+ which screen columns show any primitive this frame)
-//   columns_fill_kernel two jobs in one launch, chosen by workgroup index:
-//     columns_body      per occupied column: its compact slot list and the bin walks of trace_hash_for_light
-//                       (alt:399-500; they depend on the start bin only) -> one record per column
-//     fill_body         background for the whole row range (alt:281 -> alt:735): pure streaming
-//                       (columns_kernel, bgline_kernel -- the W distinct background shadow rays, when every ray is
-//                       traced -- and fill_kernel / fill_generic_kernel apart when other planes are asked for)
-//   render_wave_kernel  trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect alt:40-83,
-//                       Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column records,
-//                       64 pixels per wavefront, no workgroup cooperation
-//   render_overflow_kernel  the columns that overflow a record, straight from the hash, walks in-kernel
-//                       (PAR_FORCE_GENERIC=1: every column)
-// The background fill has no launch of its own: the first three launches each carry a share of it (extra
-// workgroups running fill_body), sized so that it rides along in their shadow.
+//   insert_fill_kernel      bin_insert_body   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and
+//   resolve_fill_kernel     bin_resolve_body  }   deterministic (+ which screen columns show any primitive)
+//   columns_fill_kernel     columns_body: per occupied column its compact slot list and the bin walks of
+//                           trace_hash_for_light (alt:399-500; they depend on the start bin only) -> one record
+//   render_wave_kernel      trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect
+//                           alt:40-83, Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column
+//                           records, 64 pixels per wavefront, no workgroup cooperation
+//   render_overflow_kernel  the columns that overflow a record: straight from the hash, walks in-kernel
+//                           (PAR_FORCE_GENERIC=1: every column)
+// The background fill (alt:281 -> alt:735, pure streaming) has no launch of its own: the first three launches
+// each carry a share of it (extra workgroups running fill_body), sized so that it rides along in their shadow.
+// When other planes are asked for (G-buffer, brightness, lit) or the view is not 8-pixel aligned, the hash
+// kernels run bare (bin_insert_kernel, bin_resolve_kernel, columns_kernel) and fill_kernel / fill_generic_kernel
+// follow; bgline_kernel traces the W distinct background shadow rays when every ray is to be traced.
 //
 // Float discipline: compiled with -ffp-contract=off; divisions are hipcc's default correctly-rounded fp32
 // division; min/max are the ?: forms of std::min/std::max so NaN handling follows the reference (first argument
@@ -354,16 +353,17 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// columns_kernel: one workgroup (PAR_COL_WAVES wavefronts) per occupied screen column (bx, by).
+// columns_body (columns_kernel, columns_fill_kernel): one workgroup (PAR_COL_WAVES wavefronts) per occupied screen
+// column (bx, by).
 //   A. the column's bins, front to back: compact list of the occupied ones and their slot records;
 //   B. one wavefront per occupied bin walks from it to the light as trace_hash_for_light does (alt:399-500). The
 //      probed bin sequence depends only on the start and light bins, not on the ray, so it is done ONCE per bin
 //      and frame: the slot records of every occupied bin on the way (start bin excluded, alt:471-473) are kept.
 //      A pixel whose shadow ray starts in that bin only slab-tests the short list; the reference's result is an
 //      OR over probes, so neither probe order nor duplicates matter;
-//   C. the record goes to HBM/L2 for the column's tiles; D. tiles some record can cover go onto the work list
-//      and are flagged so that fill_kernel leaves them alone.
-// A column that does not fit the record (PAR_COL_*) sends its tiles to the self-contained generic kernel.
+//   C. how the pixels are to be visited (entry rectangles or the whole tile), which entries repeat an earlier
+//      entity, how many 64-pixel chunks that makes; the record goes to HBM/L2 for the render kernel.
+// A column that does not fit the record (PAR_COL_*) goes onto the overflow list (render_overflow_kernel).
 // ------------------------------------------------------------------------------------------------------------
 
 struct ColShared {
@@ -573,9 +573,9 @@ __global__ __launch_bounds__(256) void bgline_kernel(par_grid_dev g, par_render_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// fill_kernel: background for every pixel of the row range. A pixel no primitive covers is {127,127,127,0}
-// (alt:281) times ambient (alt:735); its palette index is "none". The render kernels overwrite the tiles
-// primitives reach afterwards; the fill does not depend on the hash, so it runs beside the build.
+// fill_body / fill_kernel: background for every pixel of the row range. A pixel no primitive covers is
+// {127,127,127,0} (alt:281) times ambient (alt:735); its palette index is "none". The render kernels overwrite the
+// pixels primitives cover afterwards; the fill does not depend on the hash, so it runs beside the build.
 // Lane i of a wavefront owns pixels [8i, 8i+8) of a 512-pixel run: two 16-byte frame stores per lane, laid out so
 // that each store instruction of the wavefront covers 1 KiB contiguously, plus one 8-byte palette-index store.
 // Requires W % 8 == 0 and 16-byte aligned planes; otherwise fill_generic_kernel runs.
