@@ -45,25 +45,38 @@ def cpu_baseline(par, T, params, aabbs, light, sprite, rows):
     """Oracle (our CPU restatement of the reference, pinned to it) on the host cores: a bounded sample of the same
     workload — the row band `rows` of the same 4096x4096 frame, single thread, as the reference runs."""
     from oracle.oracle import Oracle
+    import statistics
     o = Oracle()
     grid = o.bin(params, aabbs)
     r0, r1 = rows
-    t0 = time.perf_counter()
-    gbuf, _ = o.primary(params, grid, sprite, rows=rows)
-    o.shade(params, grid, gbuf, light, rows=rows)
-    dt = time.perf_counter() - t0
+
+    def band():
+        t0 = time.perf_counter()
+        gbuf, _ = o.primary(params, grid, sprite, rows=rows)
+        o.shade(params, grid, gbuf, light, rows=rows)
+        return time.perf_counter() - t0
+
+    band()  # warm-up, excluded
+    times = [band() for _ in range(5)]
+    dt = statistics.median(times)
     single = 2.0 * (r1 - r0) * params.width / dt / 1e6
     ncores = os.cpu_count() or 1
-    t0 = time.perf_counter()
-    o.render(params, aabbs, sprite, light, nthreads=ncores, planes=("fb", "palidx"))
-    dt_all = time.perf_counter() - t0
+
+    def whole():
+        t0 = time.perf_counter()
+        o.render(params, aabbs, sprite, light, nthreads=ncores, planes=("fb", "palidx"))
+        return time.perf_counter() - t0
+
+    whole()
+    dt_all = statistics.median([whole() for _ in range(3)])
     return {
         "value": round(single, 4), "unit": "Mrays/s", "cores": 1, "kind": "port",
-        "sample": f"rows {r0}..{r1} of the same 4096x4096 / 1024-primitive frame, single thread "
-                  f"({dt:.1f} s); faithful to how the reference runs (it has no threads)",
+        "sample": f"rows {r0}..{r1} of the same {params.width}x{params.height} / {len(aabbs)}-primitive frame, single "
+                  f"thread, median of 5 after a warm-up ({dt:.2f} s each); faithful to how the reference runs (it has "
+                  "no threads)",
         "all_cores": {"value": round(2.0 * params.width * params.height / dt_all / 1e6, 3), "cores": ncores,
-                      "sample": f"whole frame, rows split over {ncores} threads ({dt_all:.1f} s); ours, not the "
-                                "reference's"},
+                      "sample": f"whole frame, rows split over {ncores} threads, median of 3 ({dt_all:.2f} s each); "
+                                "ours, not the reference's"},
     }
 
 
@@ -291,7 +304,7 @@ def main():
                                                f"{W * H - hit_pixels} background rays are {W} distinct rays "
                                                "(one per x), each traced once")
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(par, T, params, aabbs, light, sprite, (1536, 2560))
+            out["cpu_baseline"] = cpu_baseline(par, T, params, aabbs, light, sprite, (3 * H // 8, 5 * H // 8))
 
     if rank == 0:
         print(json.dumps(out))
