@@ -214,7 +214,7 @@ def main():
             "config": {"workload": f"{W}x{H}x{L} view, bin 40, {N_PRIMS} primitives (splitmix64 seed {SEED}), "
                                    f"light ({5 * W // 8},{H // 2},{L // 4}); RGBA8 frame + palette-index plane",
                        "sharding": f"row blocks over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
-                       "frames_in_flight": depth},
+                       "frames_in_flight": depth, "streams_overlap_pairwise": bool(pipe.streams_overlap)},
             "frames_per_s": round(args.steps / elapsed, 1),
             "mpix_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
             "rays": {"nominal_per_frame": int(rays_per_frame), "traced_per_frame": int(W * H + hit_pixels),

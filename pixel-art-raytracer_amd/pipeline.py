@@ -8,6 +8,8 @@ pass of the reference's render call (alt:690-760) over the scene as it was when 
 
 This is host-side plumbing over the C ABI (one `par_context` per slot); a C++ host does the same with K contexts.
 """
+import time
+
 import torch
 
 from . import Renderer, plane_bytes
@@ -24,8 +26,13 @@ class FrameSlot:
 
 
 class FramePipeline:
+    """`depth` frames in flight. HIP streams share a few hardware queues (4 by default on ROCm), and two streams on
+    the same queue do not overlap at all; which stream lands on which queue depends on what the process created
+    before. So the streams are chosen by measurement: from a pool of candidates, keep those that overlap with every
+    stream kept so far (a few dozen small probe frames each)."""
+
     def __init__(self, params, aabbs, sprites, light, depth=4, device=0, rows=None, planes=("fb", "palidx"),
-                 rows_alloc=None, sprite_ids=None):
+                 rows_alloc=None, sprite_ids=None, calibrate=True):
         dev = torch.device("cuda", device)
         r0, r1 = rows or (0, params.height)
         n_rows = rows_alloc or (r1 - r0)
@@ -36,7 +43,41 @@ class FramePipeline:
             r.set_scene(aabbs, sprites, light, sprite_ids)
             bufs = {k: torch.zeros(n_rows * params.width * plane_bytes(k), dtype=torch.uint8, device=dev)
                     for k in planes}
-            self.slots.append(FrameSlot(r, torch.cuda.Stream(device=dev), bufs, (r0, r1)))
+            self.slots.append(FrameSlot(r, None, bufs, (r0, r1)))
+        candidates = [torch.cuda.Stream(device=dev) for _ in range(depth if depth < 2 or not calibrate else 3 * depth)]
+        chosen = self._pick_streams(candidates, depth) if calibrate and depth > 1 else candidates[:depth]
+        for s, stream in zip(self.slots, chosen):
+            s.stream = stream
+        self.streams_overlap = len(chosen) == depth and getattr(self, "_all_overlap", True)
+
+    def _probe(self, sa, sb, n=24):
+        """Wall time of n frames alternating between slots 0 and 1 on streams sa and sb."""
+        a, b = self.slots[0], self.slots[1]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            s, st = (a, sa) if i % 2 == 0 else (b, sb)
+            s.renderer.render_device(s.ptrs, rows=s.rows, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def _pick_streams(self, candidates, depth):
+        first = candidates[0]
+        self._probe(first, first)  # warm-up
+        serial = min(self._probe(first, first) for _ in range(2))
+        chosen = [first]
+        for c in candidates[1:]:
+            if len(chosen) == depth:
+                break
+            if all(min(self._probe(x, c), self._probe(x, c)) < 0.85 * serial for x in chosen):
+                chosen.append(c)
+        self._all_overlap = len(chosen) == depth
+        for c in candidates:  # not enough distinct queues (or frames too short to tell): take what is there
+            if len(chosen) == depth:
+                break
+            if c not in chosen:
+                chosen.append(c)
+        return chosen
 
     def slot(self, i):
         return self.slots[i % len(self.slots)]
