@@ -96,6 +96,10 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
 int par_set_entities_ref_layout(par_context* ctx, const par_aabb* aabbs, const par_sprite* sprite_per_entity, int n);
 /* Per-frame mutation (alt:643-660 moves aabbs[0]): overwrite aabbs[first, first+n). */
 int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n);
+/* The same without blocking: the new AABBs are copied to the device in `stream` order, i.e. after the frames already
+ * enqueued on `stream` and before the next one. `stream` must be the stream this context's frames are rendered on
+ * (par_render_device); `aabbs` may be reused as soon as the call returns. For a render loop with frames in flight. */
+int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, int n, void* stream);
 /* lights[0] (alt:712-714, 729-732: the only light the reference reads). */
 int par_set_light(par_context* ctx, const par_light* light);
 
@@ -108,7 +112,7 @@ int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outp
 /* Asynchronous: enqueue on `stream` (a hipStream_t, NULL = default stream) writing DEVICE buffers. No sync.
  * Several frames may be in flight at once, each on its own context and stream (a frame alone is a chain of short
  * kernels that leaves most of the chip idle). A scene update (par_update_aabbs) waits for the context's last
- * asynchronous frame first. */
+ * asynchronous frame first; par_update_aabbs_async does not. */
 int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
                       unsigned flags);
 /* As par_render_device, bracketing the kernel groups with HIP events on `stream`; blocks until the frame is done

@@ -32,6 +32,7 @@ RENDER_COUNT_RAYS = 1 << 1
 ABI_SYMBOLS = (
     "par_status_string", "par_last_error", "par_default_params", "par_grid_dims", "par_device_count", "par_create",
     "par_destroy", "par_set_sprites", "par_set_entities", "par_set_entities_ref_layout", "par_update_aabbs",
+    "par_update_aabbs_async",
     "par_set_light", "par_render", "par_render_rows", "par_render_device", "par_render_device_timed",
     "par_graph_capture", "par_graph_stage", "par_graph_launch", "par_pick", "par_get_stats", "par_read_grid",
     "par_sprite_tile_floor", "par_scene_graybox", "par_scene_synthetic", "par_debug_line",
@@ -91,6 +92,7 @@ def lib():
         L.par_set_entities.argtypes = [vp, vp, vp, i32]
         L.par_set_entities_ref_layout.argtypes = [vp, vp, vp, i32]
         L.par_update_aabbs.argtypes = [vp, vp, i32, i32]
+        L.par_update_aabbs_async.argtypes = [vp, vp, i32, i32, vp]
         L.par_set_light.argtypes = [vp, vp]
         L.par_render.argtypes = [vp, vp, C.c_uint]
         L.par_render_rows.argtypes = [vp, i32, i32, vp, C.c_uint]
@@ -204,9 +206,14 @@ class Renderer:
         assert len(aabbs) == len(sprites)
         self._check(lib().par_set_entities_ref_layout(self._ctx, ptr(aabbs), ptr(sprites), len(aabbs)))
 
-    def update_aabbs(self, aabbs, first=0):
+    def update_aabbs(self, aabbs, first=0, stream=None):
+        """Overwrite aabbs[first, first+len). With `stream` (the hipStream_t this renderer's frames are enqueued on)
+        the copy is ordered on that stream instead of blocking."""
         aabbs = np.ascontiguousarray(aabbs, dtype=AABB)
-        self._check(lib().par_update_aabbs(self._ctx, ptr(aabbs), first, len(aabbs)))
+        if stream is None:
+            self._check(lib().par_update_aabbs(self._ctx, ptr(aabbs), first, len(aabbs)))
+        else:
+            self._check(lib().par_update_aabbs_async(self._ctx, ptr(aabbs), first, len(aabbs), C.c_void_p(stream)))
 
     def set_light(self, light):
         light = np.ascontiguousarray(light, dtype=LIGHT)

@@ -53,6 +53,11 @@ struct par_context {
     hipGraph_t graph[2] = {nullptr, nullptr};
     par_aabb* pin_aabbs = nullptr;
     par_frame_dyn* pin_dyn = nullptr;
+    par_aabb* pin_update = nullptr;   // staging of par_update_aabbs_async
+    int pin_update_capacity = 0;
+    hipEvent_t ev_update = nullptr;   // its last copy
+    bool ev_update_pending = false;
+    hipStream_t update_stream = nullptr;
     par_frame_dyn* d_dyn = nullptr;
     int graph_set = 0;
     int64_t graph_pair_bound = 0;  // (entity, bin) pairs a captured graph's launch grids can take
@@ -247,6 +252,10 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
             ctx->scratch_lit_bytes = need;
         }
         outs.lit = ctx->d_scratch_lit;
+    }
+    // an asynchronous scene update on another stream: this frame comes after it
+    if (ctx->ev_update_pending && ctx->update_stream != stream && !graph_mode) {
+        PAR_HIP(hipStreamWaitEvent(stream, ctx->ev_update, 0));
     }
     const par_bin_args b = make_bin_args(ctx, set, row_begin, row_end);
     const par_render_args r = make_render_args(ctx, set, row_begin, row_end, outs, flags, graph_mode);
@@ -444,6 +453,8 @@ void par_destroy(par_context* ctx) {
     for (int i = 0; i < 5; i++) {
         if (ctx->d_out[i]) (void)hipFree(ctx->d_out[i]);
     }
+    if (ctx->pin_update) (void)hipHostFree(ctx->pin_update);
+    if (ctx->ev_update) (void)hipEventDestroy(ctx->ev_update);
     if (ctx->pin_aabbs) (void)hipHostFree(ctx->pin_aabbs);
     if (ctx->pin_dyn) (void)hipHostFree(ctx->pin_dyn);
     for (int i = 0; i < 5; i++) {
@@ -585,8 +596,60 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     if (rc != PAR_OK) return rc;
     // a frame enqueued asynchronously by par_render_device may still be reading the AABBs: wait for it
     if (ctx->has_last_stream) PAR_HIP(hipStreamSynchronize(ctx->last_stream));
+    if (ctx->ev_update_pending) {  // ... and an asynchronous update may still be writing them
+        PAR_HIP(hipEventSynchronize(ctx->ev_update));
+        ctx->ev_update_pending = false;
+    }
     PAR_HIP(hipMemcpyAsync(ctx->d_aabbs + first, aabbs, (size_t)n * sizeof(par_aabb), hipMemcpyHostToDevice, ctx->stream));
     PAR_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; i++) {
+        ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
+        ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
+        ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
+    }
+    ctx->total_pairs = total;
+    ctx->total_cols = total_cols;
+    return PAR_OK;
+}
+
+int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, int n, void* stream_v) {
+    if (!ctx || !aabbs || first < 0 || n < 0 || !ctx->have_entities || first + n > ctx->n_entities) {
+        return fail(ctx, PAR_ERR_INVALID_ARG, "update range outside the uploaded entities");
+    }
+    hipStream_t stream = (hipStream_t)stream_v;
+    for (int i = 0; i < n; i++) {
+        if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
+    }
+    int64_t total = ctx->total_pairs, total_cols = ctx->total_cols;
+    std::vector<int32_t> np((size_t)n), nc((size_t)n);
+    for (int i = 0; i < n; i++) {
+        np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i], &nc[(size_t)i]);
+        total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
+        total_cols += nc[(size_t)i] - ctx->h_cols[(size_t)(first + i)];
+    }
+    PAR_HIP(hipSetDevice(ctx->device));
+    // the node pool grows rarely; that path frees device memory and has to wait for everything in flight
+    if (total > ctx->grid.capacity) return par_update_aabbs(ctx, aabbs, first, n);
+    // frames enqueued on another stream are not ordered with this copy: wait for them
+    if (ctx->has_last_stream && ctx->last_stream != stream) PAR_HIP(hipStreamSynchronize(ctx->last_stream));
+    if (ctx->pin_update_capacity < ctx->aabb_capacity) {
+        if (ctx->ev_update_pending) PAR_HIP(hipEventSynchronize(ctx->ev_update));
+        ctx->ev_update_pending = false;
+        if (ctx->pin_update) PAR_HIP(hipHostFree(ctx->pin_update));
+        ctx->pin_update = nullptr;
+        ctx->pin_update_capacity = 0;
+        PAR_HIP(hipHostMalloc(&ctx->pin_update, (size_t)ctx->aabb_capacity * sizeof(par_aabb), hipHostMallocDefault));
+        ctx->pin_update_capacity = ctx->aabb_capacity;
+    }
+    if (!ctx->ev_update) PAR_HIP(hipEventCreateWithFlags(&ctx->ev_update, hipEventDisableTiming));
+    // the staging area is free again once the previous update's copy has run (normally long ago)
+    if (ctx->ev_update_pending) PAR_HIP(hipEventSynchronize(ctx->ev_update));
+    std::memcpy(ctx->pin_update + first, aabbs, (size_t)n * sizeof(par_aabb));
+    PAR_HIP(hipMemcpyAsync(ctx->d_aabbs + first, ctx->pin_update + first, (size_t)n * sizeof(par_aabb),
+                           hipMemcpyHostToDevice, stream));
+    PAR_HIP(hipEventRecord(ctx->ev_update, stream));
+    ctx->ev_update_pending = true;
+    ctx->update_stream = stream;
     for (int i = 0; i < n; i++) {
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];

@@ -91,10 +91,9 @@ class FramePipeline:
     def update_aabbs(self, i, aabbs, first=0, light=None):
         """Scene mutation for frame i (alt:643-678): applied to the slot that will render it."""
         s = self.slot(i)
-        s.stream.synchronize()
-        s.renderer.update_aabbs(aabbs, first)
+        s.renderer.update_aabbs(aabbs, first, stream=s.stream.cuda_stream)  # in stream order, no wait
         if light is not None:
-            s.renderer.set_light(light)
+            s.renderer.set_light(light)  # (host state: it travels with the next frame's kernel arguments)
 
     def synchronize(self):
         for s in self.slots:
