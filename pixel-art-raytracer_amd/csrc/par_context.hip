@@ -296,9 +296,18 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
         PAR_HIP(par_launch_fill(ctx->grid, rl, stream));
     }
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
-    PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
+    bool both = false;
+    if (!ev) {  // small frames: one launch for both render kernels
+        const hipError_t e = par_launch_render_both(ctx->grid, r, col_bound, stream);
+        if (e == hipSuccess) {
+            both = true;
+        } else if (e != hipErrorNotSupported) {
+            return hip_fail(ctx, e, "par_launch_render_both");
+        }
+    }
+    if (!both) PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[4], stream));
-    PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
+    if (!both) PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
 }

@@ -160,6 +160,9 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
 // `column_bound`: an upper bound of the occupied columns.
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                              hipStream_t stream);
+// Both render kernels in one launch for small frames (else hipErrorNotSupported, nothing launched).
+hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                                  hipStream_t stream);
 // The columns that overflowed their record (every column when a.dense).
 hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                       hipStream_t stream);

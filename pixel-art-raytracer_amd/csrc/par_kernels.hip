@@ -1077,6 +1077,28 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_overflow_kernel(par_g
     }
 }
 
+// Both of the above in one launch, for small frames: there a frame is bound by its launches (the host enqueues one
+// in about 3 us, the device needs about 1.5 us between two), not by the registers the overflow path costs the others.
+// Workgroups [0, n_cols_x * parts) render the columns with a record, the rest (groups of `over_parts`) the overflow list.
+__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_dev g, par_render_args a,
+                                                                          int cost_per_part, int n_cols_x, int parts,
+                                                                          int over_parts) {
+    __shared__ WaveScratch scratch[PAR_WAVE_NW];
+    const int b = (int)blockIdx.x;
+    if (b < n_cols_x * parts) {
+        const int ci = b % n_cols_x;
+        if (ci >= g.counters[PAR_CNT_COLS] || ci >= g.col_capacity) return;
+        render_column<false>(g, a, ci, b / n_cols_x, parts, cost_per_part, nullptr);
+        return;
+    }
+    const int j = b - n_cols_x * parts;
+    const int stride = ((int)gridDim.x - n_cols_x * parts) / over_parts;
+    const int n_slow = g.counters[PAR_CNT_SLOW];
+    for (int s = j / over_parts; s < n_slow; s += stride) {
+        render_column<true>(g, a, g.slow_list[s], j % over_parts, over_parts, 1, scratch);
+    }
+}
+
 }  // namespace
 
 // The fill rides along with the first three launches when it needs only the streaming kernel (frame and
@@ -1233,6 +1255,23 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     if (a.dense) return hipSuccess;
     hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0, stream, g,
                        a, cost_per_part);
+    return hipGetLastError();
+}
+
+// Small frames: columns with a record and overflowed columns in one launch. hipErrorNotSupported (nothing launched)
+// for large frames, where the two kernels' different register needs matter.
+hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                                  hipStream_t stream) {
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
+    if (bound >= 2048 || a.dense) return hipErrorNotSupported;
+    if (bound <= 0) return hipSuccess;
+    const int parts = bound >= 512 ? 4 : 8;
+    const int cost_per_part = bound >= 512 ? 50 : 25;
+    const int over_parts = 8;
+    const int64_t over_cols = bound < 32 ? bound : 32;
+    hipLaunchKernelGGL(render_both_kernel, dim3((unsigned)(bound * parts + over_cols * over_parts)),
+                       dim3(PAR_WAVE_NW * 64), 0, stream, g, a, cost_per_part, (int)bound, parts, over_parts);
     return hipGetLastError();
 }
 

@@ -52,3 +52,23 @@ for rep in range(2):
     dt = time.perf_counter() - t0
 print(f"{'4 in flight':8s} {FRAMES / dt:9.0f} frames/s  {1e6 * dt / FRAMES:7.1f} us/frame  {2.0 * W * H * FRAMES / dt / 1e6:9.0f} Mrays/s")
 pipe.close()
+
+# (d) four contexts, each with its own captured graph (stage + launch; the slot's previous frame has to be done
+# before its staging area is rewritten)
+slots = []
+for k in range(4):
+    rr = par.Renderer(p, 0); rr.set_scene(a0, par.tile_floor(), l0)
+    fbk = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda"); palk = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.Stream()
+    rr.graph_capture({"fb": fbk.data_ptr(), "palidx": palk.data_ptr()}, stream=st.cuda_stream)
+    slots.append((rr, st, fbk, palk))
+for rep in range(2):
+    t0 = time.perf_counter()
+    for f in range(FRAMES):
+        rr, st, _, _ = slots[f % 4]
+        st.synchronize()
+        rr.graph_stage(scenes[f], 0, l0)
+        rr.graph_launch(st.cuda_stream)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"{'4 graphs in flight':8s} {FRAMES / dt:9.0f} frames/s  {1e6 * dt / FRAMES:7.1f} us/frame  {2.0 * W * H * FRAMES / dt / 1e6:9.0f} Mrays/s")
