@@ -615,6 +615,7 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
         ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
+        if (ctx->pin_aabbs) ctx->pin_aabbs[first + i] = aabbs[i];  // a captured graph uploads from here
     }
     ctx->total_pairs = total;
     ctx->total_cols = total_cols;
@@ -663,6 +664,7 @@ int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, i
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
         ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
+        if (ctx->pin_aabbs) ctx->pin_aabbs[first + i] = aabbs[i];  // a captured graph uploads from here
     }
     ctx->total_pairs = total;
     ctx->total_cols = total_cols;
@@ -793,6 +795,10 @@ int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, c
 
 int par_graph_launch(par_context* ctx, void* stream) {
     if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
+    // (the scene may also have been changed by par_update_aabbs[_async]: same limit as par_graph_stage)
+    if (ctx->total_pairs > ctx->graph_pair_bound) {
+        return fail(ctx, PAR_ERR_UNSUPPORTED, "the scene exceeds what the captured graph was sized for; capture again");
+    }
     PAR_HIP(hipGraphLaunch(ctx->graph_exec[ctx->set], (hipStream_t)stream));
     ctx->set ^= 1;
     return PAR_OK;
