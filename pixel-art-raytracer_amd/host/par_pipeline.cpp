@@ -1,0 +1,186 @@
+// par_pipeline.cpp — the frames-in-flight render loop in host C++ over the C ABI (what pipeline.py does from Python).
+//
+// K contexts with the same scene, K HIP streams, K sets of device output buffers, used round-robin like a swap chain;
+// optionally every primitive moves by the reference's +-5 steps each frame (alt:643-678), sent to the slot's context
+// with par_update_aabbs_async. The reference's host is C++, so this is the loop a maintainer would write; it also
+// shows the frame rate without an interpreter in the submit path.
+//
+//   par_pipeline [--size S] [--prims N] [--frames F] [--inflight K] [--moving] [--check]
+//
+// --check renders the last K frames once more through the blocking host path (par_render) and compares.
+// HIP streams share a few hardware queues, and two streams on one queue do not overlap: the streams are picked by a
+// short measurement from a pool of candidates (as pipeline.py does).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "par_raytracer.h"
+
+#define HIP_OK(x)                                                                        \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) {                                                          \
+            std::fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                 \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+#define PAR_OK_(ctx, x)                                                                  \
+    do {                                                                                 \
+        int rc_ = (x);                                                                   \
+        if (rc_ != PAR_OK) {                                                             \
+            std::fprintf(stderr, "%s: %s (%s)\n", #x, par_status_string(rc_), par_last_error(ctx)); \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+
+struct Slot {
+    par_context* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    par_color* fb = nullptr;
+    uint8_t* pal = nullptr;
+    par_outputs out{};
+};
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char** argv) {
+    int size = 4096, prims = 1024, frames = 2000, inflight = 4;
+    bool moving = false, check = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto next = [&](int& v) { if (i + 1 < argc) v = std::atoi(argv[++i]); };
+        if (a == "--size") next(size);
+        else if (a == "--prims") next(prims);
+        else if (a == "--frames") next(frames);
+        else if (a == "--inflight") next(inflight);
+        else if (a == "--moving") moving = true;
+        else if (a == "--check") check = true;
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (inflight < 1 || inflight > 16 || frames < 1) return 2;
+    const int W = size, H = size, L = size;
+    par_params params;
+    par_default_params(&params);
+    params.width = W; params.height = H; params.length = L;
+    std::vector<par_aabb> aabbs((size_t)prims);
+    par_light light;
+    par_scene_synthetic(prims, W, H, L, 12345, aabbs.data(), &light);
+    par_sprite sprite;
+    par_sprite_tile_floor(&sprite);
+    // +-5 or 0 per axis and frame, from a fixed little generator
+    std::vector<int16_t> vel((size_t)prims * 3);
+    uint32_t lcg = 12345u;
+    for (auto& v : vel) { lcg = lcg * 1664525u + 1013904223u; v = (int16_t)(((lcg >> 16) % 3) * 5 - 5); }
+
+    const size_t npix = (size_t)W * H;
+    std::vector<Slot> slots((size_t)inflight);
+    for (auto& s : slots) {
+        PAR_OK_(s.ctx, par_create(&params, 0, &s.ctx));
+        PAR_OK_(s.ctx, par_set_sprites(s.ctx, &sprite, 1));
+        PAR_OK_(s.ctx, par_set_entities(s.ctx, aabbs.data(), nullptr, prims));
+        PAR_OK_(s.ctx, par_set_light(s.ctx, &light));
+        HIP_OK(hipMalloc(&s.fb, npix * sizeof(par_color)));
+        HIP_OK(hipMalloc(&s.pal, npix));
+        s.out.fb = s.fb;
+        s.out.palidx = s.pal;
+    }
+    // streams that overlap pairwise
+    std::vector<hipStream_t> cand((size_t)(inflight > 1 ? 3 * inflight : 1));
+    for (auto& c : cand) HIP_OK(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+    auto probe = [&](hipStream_t sa, hipStream_t sb) -> double {
+        (void)hipDeviceSynchronize();
+        const double t0 = now_s();
+        for (int i = 0; i < 24; i++) {
+            Slot& s = slots[(size_t)(i & 1) % slots.size()];
+            par_render_device(s.ctx, (i & 1) ? sb : sa, 0, H, &s.out, 0);
+        }
+        (void)hipDeviceSynchronize();
+        return now_s() - t0;
+    };
+    std::vector<hipStream_t> chosen{cand[0]};
+    if (inflight > 1) {
+        probe(cand[0], cand[0]);
+        const double serial = std::min(probe(cand[0], cand[0]), probe(cand[0], cand[0]));
+        for (size_t c = 1; c < cand.size() && (int)chosen.size() < inflight; c++) {
+            bool ok = true;
+            for (hipStream_t x : chosen) ok = ok && std::min(probe(x, cand[c]), probe(x, cand[c])) < 0.85 * serial;
+            if (ok) chosen.push_back(cand[c]);
+        }
+        for (size_t c = 0; c < cand.size() && (int)chosen.size() < inflight; c++) {
+            if (std::find(chosen.begin(), chosen.end(), cand[c]) == chosen.end()) chosen.push_back(cand[c]);
+        }
+    }
+    for (size_t k = 0; k < slots.size(); k++) slots[k].stream = chosen[k];
+
+    std::vector<par_aabb> cur = aabbs;
+    auto scene_of = [&](int f, std::vector<par_aabb>& dst) {
+        dst = aabbs;
+        if (!moving) return;
+        for (int i = 0; i < prims; i++) {
+            dst[(size_t)i].px = (int16_t)(dst[(size_t)i].px + vel[(size_t)i * 3 + 0] * f);
+            dst[(size_t)i].py = (int16_t)(dst[(size_t)i].py + vel[(size_t)i * 3 + 1] * f);
+            dst[(size_t)i].pz = (int16_t)(dst[(size_t)i].pz + vel[(size_t)i * 3 + 2] * f);
+        }
+    };
+    auto submit = [&](int f) -> int {
+        Slot& s = slots[(size_t)f % slots.size()];
+        if (moving) {
+            scene_of(f, cur);
+            PAR_OK_(s.ctx, par_update_aabbs_async(s.ctx, cur.data(), 0, prims, s.stream));
+        }
+        PAR_OK_(s.ctx, par_render_device(s.ctx, s.stream, 0, H, &s.out, 0));
+        return 0;
+    };
+    const int warm = std::min(frames, 200);
+    for (int f = 0; f < warm; f++) if (submit(f)) return 1;
+    HIP_OK(hipDeviceSynchronize());
+    const double t0 = now_s();
+    for (int f = 0; f < frames; f++) if (submit(f)) return 1;
+    HIP_OK(hipDeviceSynchronize());
+    const double dt = now_s() - t0;
+    std::printf("{\"host\": \"C++\", \"size\": %d, \"prims\": %d, \"moving\": %s, \"frames\": %d, \"inflight\": %d, "
+                "\"us_per_frame\": %.2f, \"frames_per_s\": %.0f, \"mrays_per_s\": %.0f}\n",
+                size, prims, moving ? "true" : "false", frames, inflight, 1e6 * dt / frames, frames / dt,
+                2.0 * W * H * frames / dt / 1e6);
+
+    int bad = 0;
+    if (check) {
+        std::vector<par_color> got(npix), exp(npix);
+        std::vector<uint8_t> gpal(npix), epal(npix);
+        for (int f = std::max(0, frames - inflight); f < frames; f++) {
+            Slot& s = slots[(size_t)f % slots.size()];
+            HIP_OK(hipMemcpy(got.data(), s.fb, npix * sizeof(par_color), hipMemcpyDeviceToHost));
+            HIP_OK(hipMemcpy(gpal.data(), s.pal, npix, hipMemcpyDeviceToHost));
+            // the same scene through the blocking host path of another slot's context
+            Slot& o = slots[(size_t)(f + 1) % slots.size()];
+            std::vector<par_aabb> sc;
+            scene_of(f, sc);
+            PAR_OK_(o.ctx, par_update_aabbs(o.ctx, sc.data(), 0, prims));
+            par_outputs ho{};
+            ho.fb = exp.data();
+            ho.palidx = epal.data();
+            PAR_OK_(o.ctx, par_render(o.ctx, &ho, 0));
+            if (std::memcmp(got.data(), exp.data(), npix * sizeof(par_color)) != 0 ||
+                std::memcmp(gpal.data(), epal.data(), npix) != 0) {
+                std::fprintf(stderr, "frame %d differs from the blocking render of the same scene\n", f);
+                bad++;
+            }
+        }
+        std::printf("check: %s\n", bad ? "FAILED" : "ok");
+    }
+    for (auto& s : slots) {
+        par_destroy(s.ctx);
+        (void)hipFree(s.fb);
+        (void)hipFree(s.pal);
+    }
+    for (auto& c : cand) (void)hipStreamDestroy(c);
+    return bad ? 1 : 0;
+}

@@ -609,3 +609,19 @@ def test_async_updates_with_frames_in_flight(par, oracle, sprite, T):
         exp = oracle.render(params, scene(f), sprite, light, planes=("fb", "palidx"))
         assert np.array_equal(fb, exp["fb"].view(np.uint8)), f"frame {f}"
         assert np.array_equal(pal, exp["palidx"]), f"frame {f}"
+
+
+def test_cpp_pipeline_host(par):
+    """The frames-in-flight loop in host C++ (par_pipeline): four contexts/streams, moving primitives sent with
+    par_update_aabbs_async; its last frames equal the blocking render of the same scenes (--check)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(par.LIB_PATH), "par_pipeline")
+    assert os.path.exists(exe), "build with make -C pixel-art-raytracer_amd/csrc"
+    for extra in (["--size", "1024", "--prims", "512", "--frames", "120", "--moving"],
+                  ["--size", "640", "--prims", "100", "--frames", "60", "--inflight", "3"]):
+        p = subprocess.run([exe, "--check"] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "check: ok" in p.stdout, p.stdout + p.stderr
+        line = json.loads(p.stdout.splitlines()[0])
+        assert line["host"] == "C++" and line["frames_per_s"] > 0
