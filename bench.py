@@ -266,8 +266,10 @@ def main():
             "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
             "algorithmic_bytes_per_launch": int(dom_bytes), "avg_kernel_ms": round(dom_ms, 5),
-            "timing": "hipEvent pairs on the launch stream around each kernel group (kernels serialised for this "
-                      "measurement), mean of 30 frames; profiles/ holds the rocprofv3 per-kernel summary",
+            "timing": "hipEvent pairs on the launch stream around each kernel (kernels launched apart and one frame at "
+                      "a time for this measurement), mean of 30 frames; the bracket includes the two launch boundaries, "
+                      "about 3 us more than the dispatch duration rocprofv3 reports for the same kernel "
+                      "(profiles/*_one_frame_at_a_time_*)",
             "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); render_wave_kernel writes "
                         f"the {hit_pixels} covered pixels, fill_kernel all {W * H}",
             "note": "render_wave_kernel is VALU-issue/latency bound, not bandwidth bound (DESIGN.md section 5)",
