@@ -10,6 +10,7 @@
 //                           records, 64 pixels per wavefront, no workgroup cooperation
 //   render_overflow_kernel  the columns that overflow a record: straight from the hash, walks in-kernel
 //                           (PAR_FORCE_GENERIC=1: every column)
+//   (render_both_kernel     the last two in one launch for small frames, which are bound by their launches)
 // The background fill (alt:281 -> alt:735, pure streaming) has no launch of its own: the first three launches
 // each carry a share of it (extra workgroups running fill_body), sized so that it rides along in their shadow.
 // When other planes are asked for (G-buffer, brightness, lit) or the view is not 8-pixel aligned, the hash
