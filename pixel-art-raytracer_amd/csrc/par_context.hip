@@ -267,7 +267,8 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // it is the plain streaming one it rides along with the first three launches (timed runs keep all kernels apart
     // so that the event pairs bracket single ones).
     par_fill_plan plan;
-    const bool ride = !ev && par_plan_fill(r, &plan);
+    const bool no_fill = (flags & (1u << 28)) != 0;  // ablation (timing experiments only): no background fill
+    const bool ride = !ev && !no_fill && par_plan_fill(r, &plan);
     par_render_args rf = r;  // what rides along: the frame and palette-index planes
     rf.out.lit = nullptr;
     PAR_HIP(par_launch_bin_insert(ctx->grid, b, &rf, ride ? &plan : nullptr, stream));
@@ -287,7 +288,8 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // slower, alone and with several frames in flight: the cross-stream events cost more than the overlap gains.)
     // It follows the column kernels because, when background rays are traced, it copies their results into the lit
     // plane.
-    if (!ride) {
+    if (no_fill) {
+    } else if (!ride) {
         PAR_HIP(par_launch_fill(ctx->grid, r, stream));
     } else if (r.out.lit) {  // the lit plane of the background: after the background rays
         par_render_args rl = r;
