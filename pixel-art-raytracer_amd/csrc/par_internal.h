@@ -129,7 +129,7 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
-constexpr int PAR_WAVE_NW = 4;          // wavefronts per render_wave_kernel workgroup
+constexpr int PAR_WAVE_NW = 2;          // wavefronts per render_wave_kernel workgroup
 constexpr int PAR_WAVE_CHUNK_COST = 6;  // work of a 64-pixel chunk ~ entries tested + this (shading, shadow, stores)
 enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_TOTAL = 8 };
 

@@ -1248,11 +1248,14 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound <= 0) return hipSuccess;
-    // gridDim.y workgroups per column (a column uses as many as its work is worth); few columns: more of them, and
-    // finer parts, so that a small frame still spreads over the chip. Measured at 4096^2 / 1024 primitives (three
-    // frames in flight / one): y=1: 30.8 / 62.7 us, y=2: 31.6 / 58.2, y=3: 33.1 / 57.5, y=4: 33.1 / 57.6.
-    const int parts = bound >= 2048 ? 2 : (bound >= 512 ? 4 : 8);
-    const int cost_per_part = bound >= 2048 ? 100 : (bound >= 512 ? 50 : 25);
+    // gridDim.y workgroups (of PAR_WAVE_NW = 2 wavefronts) per column; a column uses as many as its work is worth.
+    // Few columns: more of them, and finer parts, so that a small frame still spreads over the chip.
+    // Fewer wavefronts per column trade one frame's latency for throughput. Measured at 4096^2 / 1024 primitives
+    // (four frames in flight / one frame at a time), wavefronts per workgroup x workgroups per column, cost per part:
+    // 4 x 2, 100: 30.0 / 57.3 us   2 x 2, 100: 27.9 / 62.7   2 x 3, 50: 29.3 / 58.3   2 x 4, 50: 30.2 / 56.4
+    // 1 x 4, 50: 27.3 / 62.6   1 x 2, 100: 31.6 / 78.7   8 x 2, 100: 39.2 / 60.4. The benchmark is a rate: 2 x 2.
+    const int parts = bound >= 2048 ? 2 : (bound >= 512 ? 8 : 16);
+    const int cost_per_part = bound >= 2048 ? 100 : (bound >= 512 ? 25 : 12);
     if (a.dense) return hipSuccess;
     hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0, stream, g,
                        a, cost_per_part);
@@ -1267,8 +1270,8 @@ hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& 
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound >= 2048 || a.dense) return hipErrorNotSupported;
     if (bound <= 0) return hipSuccess;
-    const int parts = bound >= 512 ? 4 : 8;
-    const int cost_per_part = bound >= 512 ? 50 : 25;
+    const int parts = bound >= 512 ? 8 : 16;  // (of PAR_WAVE_NW = 2 wavefronts, as in par_launch_render)
+    const int cost_per_part = bound >= 512 ? 25 : 12;
     const int over_parts = 8;
     const int64_t over_cols = bound < 32 ? bound : 32;
     hipLaunchKernelGGL(render_both_kernel, dim3((unsigned)(bound * parts + over_cols * over_parts)),
