@@ -761,7 +761,7 @@ template <bool GENERIC>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
                                              const ColumnRegs& cr, uint64_t dup, const par_frame_dyn& dyn,
                                              int n_entries, int n_nb, int bx, int by, int own, int col, int row,
-                                             bool valid, int lane, WaveScratch* ws) {
+                                             int row_lo, int row_hi, bool valid, int lane, WaveScratch* ws) {
     const int W = a.W, H = a.H;
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
@@ -815,6 +815,9 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
                 // depth: it can neither improve `closest` (strict compare, alt:344) nor be the first to cover.
                 if ((dup >> e) & 1) continue;
                 const par_slot rec = slot_of_lane(cr.ent, e);
+                // (wave-uniform) an entry whose rows miss the chunk's rows [row_lo, row_hi] covers none of its
+                // pixels: dense columns list many entries, a chunk meets few of them
+                if (row_hi < H - (rec.py + rec.ey + rec.pz + rec.ez) || row_lo >= H - (rec.py + rec.pz)) continue;
                 // a lane whose pixel an earlier entry owns has nothing to do in this pass
                 if (first_cover < own) done = true;  // (never in tile mode: own = -1)
                 if (__all(done)) break;  // wavefront early-out
@@ -1046,8 +1049,12 @@ __device__ __forceinline__ void render_column(const par_grid_dev& g, const par_r
             const int pidx = c * 64 + lane;
             const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
             const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
-            render_chunk<GENERIC>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, pidx < area, lane,
-                                  ws ? ws + wave : nullptr);
+            // the chunk's first and last row (wave-uniform)
+            const int p_first = c * 64, p_last = min(p_first + 63, area - 1);
+            const int row_lo = ry0 + ((rw == 1) ? p_first : (int)__umulhi((uint32_t)p_first, magic_w));
+            const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
+            render_chunk<GENERIC>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi,
+                                  pidx < area, lane, ws ? ws + wave : nullptr);
         }
     }
 }
