@@ -25,6 +25,7 @@ struct par_context {
     int64_t total_pairs = 0;
     std::vector<int32_t> h_cols;   // screen columns (bx, by) each entity reaches: its pairs without the z factor
     int64_t total_cols = 0;        // >= the occupied columns of the frame
+    int64_t total_items = 0;       // >= the render work items (64-pixel chunks) of the frame, see items_of
     int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
     bool have_light = false, have_entities = false;
     par_light light{};
@@ -61,6 +62,7 @@ struct par_context {
     par_frame_dyn* d_dyn = nullptr;
     int graph_set = 0;
     int64_t graph_pair_bound = 0;  // (entity, bin) pairs a captured graph's launch grids can take
+    int64_t graph_item_bound = 0;  // ... and render work items
 
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     par_frame_stats stats{};
@@ -111,6 +113,26 @@ bool extent_ok(const par_aabb& a) {
     return a.ex >= 0 && a.ey >= 0 && a.ez >= 0 && a.ex <= PAR_SPRITE_W && (int)a.ey + (int)a.ez <= PAR_SPRITE_H;
 }
 
+// Render work items (64-pixel chunks) an entity can cause: its sprite rectangle (ex wide, ey + ez tall, alt:310-317)
+// is cut by the `cols` screen columns it reaches into that many pieces, each visited in whole chunks:
+// sum of ceil(area_i / 64) <= floor(area / 64) + pieces. (A column switches to visiting its whole tile only when that
+// takes fewer chunks.)
+int64_t items_of(const par_aabb& a, int32_t cols) {
+    return cols > 0 ? (int64_t)a.ex * ((int)a.ey + (int)a.ez) / 64 + cols : 0;
+}
+
+// ... and what a frame can hold at most: every column visited as a whole tile.
+int64_t max_items(const par_context* c) {
+    const int64_t B = c->params.bin_size;
+    return (int64_t)c->gx * c->gy * ((B * B + 63) / 64);
+}
+
+bool items_fit(const par_context* c, int64_t items, int64_t cols) {
+    const int64_t B = c->params.bin_size;
+    cols = std::min<int64_t>(cols, (int64_t)c->gx * c->gy);
+    return std::min(items, (cols / PAR_ITEM_SHARDS + 1) * ((B * B + 63) / 64)) <= c->grid.item_capacity;
+}
+
 void free_pool(par_context* c) {
     for (int s = 0; s < 2; s++) {
         if (c->grid.node_entity[s]) (void)hipFree(c->grid.node_entity[s]);
@@ -122,6 +144,25 @@ void free_pool(par_context* c) {
     c->grid.colrec = nullptr;
     c->grid.col_capacity = 0;
     c->grid.capacity = 0;
+}
+
+// One shard of the render work-item list holds the items of the columns whose index is congruent to it: at most
+// every item of the frame, and at most its share of the occupied columns (<= `cols`), each visited as a whole tile.
+int ensure_items(par_context* ctx, int64_t items, int64_t cols) {
+    const int64_t B = ctx->params.bin_size;
+    cols = std::min<int64_t>(cols, (int64_t)ctx->gx * ctx->gy);
+    const int64_t need = std::min(items, (cols / PAR_ITEM_SHARDS + 1) * ((B * B + 63) / 64));
+    if (need <= ctx->grid.item_capacity) return PAR_OK;
+    if (ctx->graph_exec[0]) return fail(ctx, PAR_ERR_UNSUPPORTED, "work-item list would grow under a captured graph; capture again");
+    const int64_t cap = std::max<int64_t>(need + need / 2, 1 << 10);
+    if (cap > 0x3FFFFFFF / PAR_ITEM_SHARDS) return fail(ctx, PAR_ERR_UNSUPPORTED, "too many render work items");
+    PAR_HIP(hipDeviceSynchronize());
+    if (ctx->grid.items) PAR_HIP(hipFree(ctx->grid.items));
+    ctx->grid.items = nullptr;
+    ctx->grid.item_capacity = 0;
+    PAR_HIP(hipMalloc(&ctx->grid.items, (size_t)cap * PAR_ITEM_SHARDS * sizeof(uint2)));
+    ctx->grid.item_capacity = (int32_t)cap;
+    return PAR_OK;
 }
 
 // Wipe both head/count sets and the node counters (context creation, and whenever the node pool is replaced and
@@ -224,8 +265,9 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     return a;
 }
 
-par_bin_args make_bin_args(const par_context* c, int set, int row_begin, int row_end) {
+par_bin_args make_bin_args(const par_context* c, int set, int row_begin, int row_end, unsigned flags) {
     par_bin_args b{};
+    b.flags = flags;
     b.by_lo = row_begin / c->params.bin_size;
     b.by_hi = (row_end - 1) / c->params.bin_size;
     b.W = c->params.width; b.H = c->params.height; b.L = c->params.length; b.B = c->params.bin_size;
@@ -257,7 +299,7 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     if (ctx->ev_update_pending && ctx->update_stream != stream && !graph_mode) {
         PAR_HIP(hipStreamWaitEvent(stream, ctx->ev_update, 0));
     }
-    const par_bin_args b = make_bin_args(ctx, set, row_begin, row_end);
+    const par_bin_args b = make_bin_args(ctx, set, row_begin, row_end, flags);
     const par_render_args r = make_render_args(ctx, set, row_begin, row_end, outs, flags, graph_mode);
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
@@ -298,16 +340,19 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
         PAR_HIP(par_launch_fill(ctx->grid, rl, stream));
     }
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
+    // work items <= what the entities can cause one by one, and <= every column of the rendered rows as a whole tile
+    const int64_t item_cap_rows = max_items(ctx) / ctx->gy * (r.by_hi - r.by_lo + 1);
+    const int64_t item_bound = std::min(graph_mode ? ctx->graph_item_bound : ctx->total_items, item_cap_rows);
     bool both = false;
     if (!ev) {  // small frames: one launch for both render kernels
-        const hipError_t e = par_launch_render_both(ctx->grid, r, col_bound, stream);
+        const hipError_t e = par_launch_render_both(ctx->grid, r, col_bound, item_bound, stream);
         if (e == hipSuccess) {
             both = true;
         } else if (e != hipErrorNotSupported) {
             return hip_fail(ctx, e, "par_launch_render_both");
         }
     }
-    if (!both) PAR_HIP(par_launch_render(ctx->grid, r, col_bound, stream));
+    if (!both) PAR_HIP(par_launch_render(ctx->grid, r, item_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[4], stream));
     if (!both) PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
@@ -409,8 +454,13 @@ int par_create(const par_params* params, int device, par_context** out) {
     }
     if ((e = hipMalloc(&ctx->grid.col_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.counters, PAR_CNT_TOTAL * sizeof(int32_t))) != hipSuccess) return bail(e);
+    {
+        const size_t bytes = (size_t)PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE * sizeof(int32_t);
+        if ((e = hipMalloc(&ctx->grid.item_counters, bytes)) != hipSuccess) return bail(e);
+        if ((e = hipMemset(ctx->grid.item_counters, 0, bytes)) != hipSuccess) return bail(e);
+    }
     if (const char* dbg = std::getenv("PAR_DEBUG_STAMPS"); dbg && dbg[0] == '1') {
-        const size_t bytes = (size_t)2 * PAR_STAMP_WGS * PAR_STAMP_SLOTS * sizeof(unsigned long long);
+        const size_t bytes = (size_t)PAR_STAMP_ROWS * PAR_STAMP_WGS * PAR_STAMP_SLOTS * sizeof(unsigned long long);
         if ((e = hipMalloc(&ctx->grid.stamps, bytes)) != hipSuccess) return bail(e);
         if ((e = hipMemset(ctx->grid.stamps, 0, bytes)) != hipSuccess) return bail(e);
     }
@@ -432,7 +482,7 @@ int par_create(const par_params* params, int device, par_context** out) {
         par_destroy(ctx);
         return PAR_ERR_HIP;
     }
-    if (ensure_pool(ctx, 1) != PAR_OK) {
+    if (ensure_pool(ctx, 1) != PAR_OK || ensure_items(ctx, 1, 1) != PAR_OK) {
         par_destroy(ctx);
         return PAR_ERR_OOM;
     }
@@ -452,7 +502,7 @@ void par_destroy(par_context* ctx) {
         if (ctx->grid.colflag[s]) (void)hipFree(ctx->grid.colflag[s]);
     }
     void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.slow_list, ctx->grid.stamps, ctx->grid.bgwalk,
-                     ctx->grid.bglit, ctx->d_scratch_lit};
+                     ctx->grid.bglit, ctx->d_scratch_lit, ctx->grid.items, ctx->grid.item_counters};
     for (void* p : lists) {
         if (p) (void)hipFree(p);
     }
@@ -526,15 +576,18 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     PAR_HIP(hipDeviceSynchronize());
     drop_graphs(ctx);
     std::vector<int32_t> pairs((size_t)n), cols((size_t)n);
-    int64_t total = 0, total_cols = 0;
+    int64_t total = 0, total_cols = 0, total_items = 0;
     for (int i = 0; i < n; i++) {
         const int64_t k = pairs_of(ctx, aabbs[i], &cols[(size_t)i]);
         if (k > 0x7FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "entity spans too many bins");
         pairs[(size_t)i] = (int32_t)k;
         total += k;
         total_cols += cols[(size_t)i];
+        total_items += items_of(aabbs[i], cols[(size_t)i]);
     }
     int rc = ensure_pool(ctx, total);
+    if (rc != PAR_OK) return rc;
+    rc = ensure_items(ctx, total_items, total_cols);
     if (rc != PAR_OK) return rc;
     if (n > ctx->aabb_capacity) {
         if (ctx->d_aabbs) PAR_HIP(hipFree(ctx->d_aabbs));
@@ -555,6 +608,7 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     ctx->total_pairs = total;
     ctx->h_cols.swap(cols);
     ctx->total_cols = total_cols;
+    ctx->total_items = total_items;
     ctx->n_entities = n;
     ctx->max_sprite_id = max_id;
     ctx->have_entities = true;
@@ -596,14 +650,18 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
     std::vector<int32_t> np((size_t)n), nc((size_t)n);
-    int64_t total_cols = ctx->total_cols;
+    int64_t total_cols = ctx->total_cols, total_items = ctx->total_items;
     for (int i = 0; i < n; i++) {
         np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i], &nc[(size_t)i]);
         total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
         total_cols += nc[(size_t)i] - ctx->h_cols[(size_t)(first + i)];
+        total_items += items_of(aabbs[i], nc[(size_t)i]) -
+                       items_of(ctx->h_aabbs[(size_t)(first + i)], ctx->h_cols[(size_t)(first + i)]);
     }
     PAR_HIP(hipSetDevice(ctx->device));
     int rc = ensure_pool(ctx, total);
+    if (rc != PAR_OK) return rc;
+    rc = ensure_items(ctx, total_items, total_cols);
     if (rc != PAR_OK) return rc;
     // a frame enqueued asynchronously by par_render_device may still be reading the AABBs: wait for it
     if (ctx->has_last_stream) PAR_HIP(hipStreamSynchronize(ctx->last_stream));
@@ -621,6 +679,7 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     }
     ctx->total_pairs = total;
     ctx->total_cols = total_cols;
+    ctx->total_items = total_items;
     return PAR_OK;
 }
 
@@ -632,16 +691,21 @@ int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, i
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    int64_t total = ctx->total_pairs, total_cols = ctx->total_cols;
+    int64_t total = ctx->total_pairs, total_cols = ctx->total_cols, total_items = ctx->total_items;
     std::vector<int32_t> np((size_t)n), nc((size_t)n);
     for (int i = 0; i < n; i++) {
         np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i], &nc[(size_t)i]);
         total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
         total_cols += nc[(size_t)i] - ctx->h_cols[(size_t)(first + i)];
+        total_items += items_of(aabbs[i], nc[(size_t)i]) -
+                       items_of(ctx->h_aabbs[(size_t)(first + i)], ctx->h_cols[(size_t)(first + i)]);
     }
     PAR_HIP(hipSetDevice(ctx->device));
-    // the node pool grows rarely; that path frees device memory and has to wait for everything in flight
-    if (total > ctx->grid.capacity) return par_update_aabbs(ctx, aabbs, first, n);
+    // the node pool and the item list grow rarely; that path frees device memory and has to wait for everything in
+    // flight
+    if (total > ctx->grid.capacity || !items_fit(ctx, total_items, total_cols)) {
+        return par_update_aabbs(ctx, aabbs, first, n);
+    }
     // frames enqueued on another stream are not ordered with this copy: wait for them
     if (ctx->has_last_stream && ctx->last_stream != stream) PAR_HIP(hipStreamSynchronize(ctx->last_stream));
     if (ctx->pin_update_capacity < ctx->aabb_capacity) {
@@ -670,6 +734,7 @@ int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, i
     }
     ctx->total_pairs = total;
     ctx->total_cols = total_cols;
+    ctx->total_items = total_items;
     return PAR_OK;
 }
 
@@ -741,6 +806,14 @@ int par_graph_capture(par_context* ctx, void* stream_v, int row_begin, int row_e
     ctx->graph_pair_bound = ctx->total_pairs * 2 + 4096;
     rc = ensure_pool(ctx, ctx->graph_pair_bound);
     if (rc != PAR_OK) return rc;
+    {   // wherever the entities move: each reaches at most this many screen columns (cull and ranges of alt:212-240)
+        const int B = ctx->params.bin_size;
+        const int64_t cols_max = (int64_t)((PAR_SPRITE_W + B - 1) / B + 1) * ((PAR_SPRITE_H + B - 1) / B + 1);
+        ctx->graph_item_bound = std::min<int64_t>(
+            (int64_t)ctx->n_entities * ((int64_t)PAR_SPRITE_W * PAR_SPRITE_H / 64 + cols_max), max_items(ctx));
+    }
+    rc = ensure_items(ctx, ctx->graph_item_bound, ctx->graph_pair_bound);
+    if (rc != PAR_OK) return rc;
     if (!ctx->pin_aabbs) {
         PAR_HIP(hipHostMalloc(&ctx->pin_aabbs, (size_t)std::max(ctx->aabb_capacity, 1) * sizeof(par_aabb), hipHostMallocDefault));
         PAR_HIP(hipHostMalloc(&ctx->pin_dyn, sizeof(par_frame_dyn), hipHostMallocDefault));
@@ -782,6 +855,8 @@ int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, c
     for (int i = 0; i < n; i++) {
         int32_t nc = 0;
         ctx->h_pairs[(size_t)(first + i)] = (int32_t)pairs_of(ctx, aabbs[i], &nc);
+        ctx->total_items += items_of(aabbs[i], nc) -
+                            items_of(ctx->h_aabbs[(size_t)(first + i)], ctx->h_cols[(size_t)(first + i)]);
         ctx->total_cols += nc - ctx->h_cols[(size_t)(first + i)];
         ctx->h_cols[(size_t)(first + i)] = nc;
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
@@ -844,7 +919,7 @@ int par_get_stats(par_context* ctx, par_frame_stats* stats) {
 // Internal profiling aid (not part of the public header): copy the debug stamp buffer out (PAR_DEBUG_STAMPS=1).
 int par_debug_read_stamps(par_context* ctx, unsigned long long* out, size_t count) {
     if (!ctx || !out || !ctx->grid.stamps) return PAR_ERR_NOT_READY;
-    const size_t n = (size_t)2 * PAR_STAMP_WGS * PAR_STAMP_SLOTS;
+    const size_t n = (size_t)PAR_STAMP_ROWS * PAR_STAMP_WGS * PAR_STAMP_SLOTS;
     if (hipDeviceSynchronize() != hipSuccess) return PAR_ERR_HIP;
     if (hipMemcpy(out, ctx->grid.stamps, (count < n ? count : n) * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return PAR_ERR_HIP;
     return PAR_OK;

@@ -19,6 +19,7 @@ static_assert(sizeof(par_slot) == 16, "slot record must stay 16 bytes");
 
 constexpr int PAR_STAMP_SLOTS = 8;      // time stamps per workgroup in the debug stamp buffer
 constexpr int PAR_STAMP_WGS = 8192;     // workgroups per kernel that get a row in it
+constexpr int PAR_STAMP_ROWS = 5;       // kernels of a frame
 
 // Kernel geometry (see DESIGN.md "kernels").
 constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count (bin coordinates are kept in int16)
@@ -90,12 +91,15 @@ struct par_grid_dev {
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
     int32_t* counters;        // [PAR_CNT_TOTAL]: occupied columns, overflowed columns (reset by insert)
     par_colrec* colrec;       // [col_capacity] indexed like col_list
+    uint2* items;             // [PAR_ITEM_SHARDS * item_capacity] render work items: one 64-pixel chunk each
+    int32_t* item_counters;   // [PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE] items per shard (reset by insert)
     int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
     par_bgwalk* bgwalk;       // [gx] shadow walks of the background rays (traced only on request)
     uint8_t* bglit;           // [width] result of the background ray of screen column x
     unsigned long long* stamps;  // debug (PAR_DEBUG_STAMPS=1): per workgroup phase time stamps, else nullptr
     int32_t capacity;
     int32_t col_capacity;
+    int32_t item_capacity;    // work items one shard of `items` holds
 };
 
 struct par_bin_args {
@@ -103,6 +107,7 @@ struct par_bin_args {
     int32_t n;
     int32_t set;             // which head/count/node/colflag set this frame uses
     int32_t by_lo, by_hi;    // bin rows [by_lo, by_hi] the render of this frame touches (column-list filter)
+    uint32_t flags;          // render flags (bit 29: debug time stamps)
     const par_aabb* aabbs;
 };
 
@@ -129,8 +134,17 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
-constexpr int PAR_WAVE_NW = 2;          // wavefronts per render_wave_kernel workgroup
-constexpr int PAR_WAVE_CHUNK_COST = 6;  // work of a 64-pixel chunk ~ entries tested + this (shading, shadow, stores)
+constexpr int PAR_WAVE_NW = 2;          // wavefronts per render workgroup
+// Render work items: columns_kernel lists every 64-pixel chunk of every column with a record as one item
+// {column index, (pass << 16) | chunk of the pass}; pass = the entry whose rectangle is visited, PAR_ITEM_TILE = the
+// whole tile. The list is kept in PAR_ITEM_SHARDS shards (column index mod shards), each with its own counter, so
+// that the column workgroups' appends do not queue up on one address; wavefront w of the render launch takes items
+// w / shards, + waves / shards, ... of shard w mod shards.
+constexpr int PAR_ITEM_SHARD_BITS = 6;
+constexpr int PAR_ITEM_SHARDS = 1 << PAR_ITEM_SHARD_BITS;
+constexpr int PAR_ITEM_COUNTER_STRIDE = 32;  // int32 words between two shard counters: one 128-byte line each
+constexpr uint32_t PAR_ITEM_TILE = 0xFFFFu;
+constexpr uint32_t PAR_ITEM_NONE = 0xFFFFFFFFu;  // a reserved item slot whose column went to the overflow list
 enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_TOTAL = 8 };
 
 // The background fill split over the frame's first three launches: 512-pixel chunks [cut[i], cut[i+1]) go with
@@ -157,12 +171,12 @@ hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args&
 // Background for every pixel of the row range; the render kernel then overwrites the pixels primitives cover.
 // Independent of the hash.
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream);
-// `column_bound`: an upper bound of the occupied columns.
-hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+// `item_bound`: an upper bound of the frame's work items (64-pixel chunks of the columns with a record).
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
                              hipStream_t stream);
 // Both render kernels in one launch for small frames (else hipErrorNotSupported, nothing launched).
 hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
-                                  hipStream_t stream);
+                                  int64_t item_bound, hipStream_t stream);
 // The columns that overflowed their record (every column when a.dense).
 hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                       hipStream_t stream);

@@ -4,10 +4,11 @@
 //   insert_fill_kernel      bin_insert_body   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and
 //   resolve_fill_kernel     bin_resolve_body  }   deterministic (+ which screen columns show any primitive)
 //   columns_fill_kernel     columns_body: per occupied column its compact slot list and the bin walks of
-//                           trace_hash_for_light (alt:399-500; they depend on the start bin only) -> one record
-//   render_wave_kernel      trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect
-//                           alt:40-83, Vector::normalize spr:28-35, Color::operator* spr:8-16 -- from the column
-//                           records, 64 pixels per wavefront, no workgroup cooperation
+//                           trace_hash_for_light (alt:399-500; they depend on the start bin only) -> one record,
+//                           and one work item per 64-pixel chunk of the column's visit
+//   render_items_kernel     trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect
+//                           alt:40-83, Vector::normalize spr:28-35, Color::operator* spr:8-16 -- one wavefront
+//                           per work item, from the column records, no workgroup cooperation
 //   render_overflow_kernel  the columns that overflow a record: straight from the hash, walks in-kernel
 //                           (PAR_FORCE_GENERIC=1: every column)
 //   (render_both_kernel     the last two in one launch for small frames, which are bound by their launches)
@@ -28,8 +29,10 @@ namespace {
 
 // Debug time stamps (PAR_DEBUG_STAMPS=1): lane 0 of a workgroup notes the 100 MHz wall clock at phase boundaries
 // into a buffer of its own; nothing the kernels compute reads it. `k` = kernel row, `i` = stamp slot.
-__device__ __forceinline__ void stamp(const par_grid_dev& g, int k, int i) {
-    if (g.stamps && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
+// Rows: 0 insert, 1 resolve, 2 columns (slots 0..4 are its phases), 3 render, 4 overflow; slot 0 = the workgroup's
+// start, slot 7 = its end. Only frames rendered with flag bit 29 are stamped.
+__device__ __forceinline__ void stamp(const par_grid_dev& g, uint32_t flags, int k, int i) {
+    if (g.stamps && (flags & (1u << 29)) && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
         g.stamps[((size_t)k * PAR_STAMP_WGS + blockIdx.x) * PAR_STAMP_SLOTS + i] = __builtin_amdgcn_s_memrealtime();
     }
 }
@@ -78,6 +81,7 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
         g.colflag[o][b / g.gz] = 0;
     }
     if (tid < PAR_CNT_TOTAL) g.counters[tid] = 0;
+    if (tid < PAR_ITEM_SHARDS) g.item_counters[tid * PAR_ITEM_COUNTER_STRIDE] = 0;
 
     const int W = a.W, H = a.H, L = a.L, B = a.B;
     const int lane = threadIdx.x & 63;
@@ -142,7 +146,9 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
 
 template <int ENT>
 __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin_args a) {
+    stamp(g, a.flags, 0, 0);
     bin_insert_body<ENT>(g, a, (int)blockIdx.x, (int)gridDim.x);
+    stamp(g, a.flags, 0, 7);
 }
 
 __device__ __forceinline__ void bin_resolve_body(const par_grid_dev& g, const par_bin_args& a, int block) {
@@ -204,7 +210,9 @@ __device__ __forceinline__ void bin_resolve_body(const par_grid_dev& g, const pa
 }
 
 __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bin_args a) {
+    stamp(g, a.flags, 1, 0);
     bin_resolve_body(g, a, (int)blockIdx.x);
+    stamp(g, a.flags, 1, 7);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -377,6 +385,7 @@ struct ColShared {
     int32_t n_walk;
     int32_t overflow;
     int32_t chunks;
+    int32_t tile_mode;
     uint32_t dup[2];
 };
 
@@ -398,12 +407,12 @@ __device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_re
         return;
     }
     const int ci = block;
-    stamp(g, 0, 0);
+    stamp(g, a.flags, 2, 0);
     // the launch is sized by an upper bound of the occupied columns; both loads are issued together
     const int n_cols = g.counters[PAR_CNT_COLS];
     const int col = g.col_list[ci];
     if (ci >= n_cols) return;
-    stamp(g, 0, 1);
+    stamp(g, a.flags, 2, 1);
     const int bx = col / g.gy, by = col - (col / g.gy) * g.gy;
     const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
     if (tid == 0) {
@@ -443,7 +452,44 @@ __device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_re
     }
     __syncthreads();
     const int n_nb = nb_base, n_entries = ent_base;
-    stamp(g, 0, 2);
+    stamp(g, a.flags, 2, 2);
+
+    // ---- how the render kernel should visit the column's pixels: entry rectangle by entry rectangle when they
+    // cover little of it (the lanes of a 64-pixel chunk are then nearly all covered pixels), otherwise the whole
+    // tile. An entry that repeats an earlier entry's entity (the same AABB in another bin of the column) has the
+    // same rectangle and owns no pixel: it is marked and skipped. Every 64-pixel chunk of the visit becomes one
+    // work item of the render launch. All of it is wavefront 0's (at most PAR_COL_ENT <= 64 entries: one per lane).
+    // The column's share of its shard of the item list is reserved here, BEFORE the walks, with one atomic on one of
+    // PAR_ITEM_SHARDS words that lie a cache line apart: its result is needed only after the walks, which hide its
+    // latency.
+    const int c0 = bx * a.B, tw = min(a.B, a.W - c0);
+    const int rows_lo = max(by * a.B, a.row_begin), rows_hi = min(min((by + 1) * a.B, a.H), a.row_end);
+    const int tile_chunks = (tw * max(rows_hi - rows_lo, 0) + 63) >> 6;
+    const int shard = ci & (PAR_ITEM_SHARDS - 1);
+    int my_chunks = 0, first_item = 0, n_items = 0, item_base = 0, tile_mode = 0;
+    if (wave == 0) {
+        bool dup = false;
+        if (!sm.overflow && lane < n_entries) {
+            const par_slot r = sm.entries[lane];
+            for (int e = 0; e < lane; e++) dup = dup || (sm.entries[e].entity == r.entity);
+            const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
+            const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
+            if (!dup && w > 0 && h > 0) my_chunks = (w * h + 63) >> 6;  // every visit costs whole wavefronts
+        }
+        const uint64_t dup_mask = __ballot(dup);
+        const int incl = wave_incl_scan_i(my_chunks, lane);
+        const int pass_chunks = __shfl(incl, 63);
+        first_item = incl - my_chunks;
+        tile_mode = (pass_chunks >= tile_chunks) ? 1 : 0;
+        n_items = sm.overflow ? 0 : (tile_mode ? tile_chunks : pass_chunks);
+        if (lane == 0) {
+            if (n_items > 0) item_base = atomicAdd(&g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], n_items);
+            sm.chunks = n_items;
+            sm.dup[0] = (uint32_t)dup_mask;
+            sm.dup[1] = (uint32_t)(dup_mask >> 32);
+            sm.tile_mode = tile_mode;
+        }
+    }
 
     // ---- B: the shadow walks, one wavefront per occupied bin --------------------------------------------------
     if (!sm.overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
@@ -474,52 +520,47 @@ __device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_re
         }
     }
     __syncthreads();
-    const bool overflow = sm.overflow != 0;
-    stamp(g, 0, 3);
+    stamp(g, a.flags, 2, 3);
 
-    // ---- how the render kernel should visit the column's pixels: entry rectangle by entry rectangle when they
-    // cover little of it (the lanes of a 64-pixel chunk are then nearly all covered pixels), otherwise the whole
-    // tile. An entry that repeats an earlier entry's entity (the same AABB in another bin of the column) has the
-    // same rectangle and owns no pixel: it is marked and skipped. ----------------------------------------------
-    if (tid == 0) {
-        sm.chunks = 0;
-        sm.dup[0] = sm.dup[1] = 0;
-    }
-    __syncthreads();
-    const int c0 = bx * a.B, tw = min(a.B, a.W - c0);
-    const int rows_lo = max(by * a.B, a.row_begin), rows_hi = min(min((by + 1) * a.B, a.H), a.row_end);
-    if (!overflow && tid < n_entries) {
-        const par_slot r = sm.entries[tid];
-        bool dup = false;
-        for (int e = 0; e < tid; e++) dup = dup || (sm.entries[e].entity == r.entity);
-        const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
-        const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
-        if (dup) {
-            atomicOr(&sm.dup[tid >> 5], 1u << (tid & 31));
-        } else if (w > 0 && h > 0) {
-            atomicAdd(&sm.chunks, (w * h + 63) >> 6);  // every visit costs whole wavefronts
+    // ---- the column's work items (none of them usable when a walk overflowed the record meanwhile, or when the
+    // shard is full: the host sizes a shard for every item of the frame, so that is belt and braces) --------------
+    if (wave == 0 && n_items > 0) {
+        item_base = __shfl(item_base, 0);
+        const bool usable = !sm.overflow && item_base + n_items <= g.item_capacity;
+        uint2* dst = g.items + (size_t)shard * g.item_capacity + item_base;
+        const uint32_t id = usable ? (uint32_t)ci : PAR_ITEM_NONE;
+        if (tile_mode) {
+            for (int k = lane; k < n_items; k += 64) {
+                if (item_base + k < g.item_capacity) dst[k] = make_uint2(id, (PAR_ITEM_TILE << 16) | (uint32_t)k);
+            }
+        } else {
+            for (int k = 0; k < my_chunks; k++) {
+                if (item_base + first_item + k < g.item_capacity) {
+                    dst[first_item + k] = make_uint2(id, ((uint32_t)lane << 16) | (uint32_t)k);
+                }
+            }
         }
+        if (!usable && lane == 0) sm.overflow = 1;
     }
     __syncthreads();
-    const int tile_chunks = (tw * max(rows_hi - rows_lo, 0) + 63) >> 6;
-    const int tile_mode = (sm.chunks >= tile_chunks) ? 1 : 0;
+    const bool overflow_final = sm.overflow != 0;
 
     // ---- C: the record ----------------------------------------------------------------------------------------
     if (ci < g.col_capacity) {
         par_colrec* rec = g.colrec + ci;
         if (tid == 0) {
-            rec->n_nb = (int16_t)(overflow ? 0 : n_nb);
-            rec->n_entries = (int16_t)(overflow ? 0 : n_entries);
+            rec->n_nb = (int16_t)(overflow_final ? 0 : n_nb);
+            rec->n_entries = (int16_t)(overflow_final ? 0 : n_entries);
             rec->n_walk = (int16_t)sm.n_walk;
-            rec->overflow = overflow ? 1 : 0;
+            rec->overflow = overflow_final ? 1 : 0;
             rec->bx = (int16_t)bx;
             rec->by = (int16_t)by;
-            rec->tile_mode = tile_mode;
-            rec->chunks = tile_mode ? tile_chunks : sm.chunks;
+            rec->tile_mode = sm.tile_mode;
+            rec->chunks = sm.chunks;
             rec->dup_lo = sm.dup[0];
             rec->dup_hi = sm.dup[1];
         }
-        if (!overflow) {
+        if (!overflow_final) {
             if (tid < n_nb) rec->nb[tid] = sm.nb[tid];
             if (tid < n_entries) {
                 rec->entries[tid] = sm.entries[tid];
@@ -527,13 +568,14 @@ __device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_re
             }
         }
     }
-    if (overflow && tid == 0) g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;  // the exception
-    stamp(g, 0, 4);
+    if (overflow_final && tid == 0) g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;  // the exception
+    stamp(g, a.flags, 2, 4);
 }
 
 __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a) {
     __shared__ ColShared sm;
     columns_body(g, a, sm, (int)blockIdx.x, (int)gridDim.x);
+    stamp(g, a.flags, 2, 7);
 }
 
 __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, int sx, int sy,
@@ -640,28 +682,34 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_fill_kernel(par_gr
     if ((int)blockIdx.x < n_col) {
         columns_body(g, a, sm, (int)blockIdx.x, n_col);
     } else {
+        stamp(g, a.flags, 2, 0);
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col, (int)gridDim.x - n_col, part);
     }
+    stamp(g, a.flags, 2, 7);
 }
 
 // The same for the two short kernels of the hash build: each carries a smaller share of the fill.
 template <int ENT>
 __global__ __launch_bounds__(256) void insert_fill_kernel(par_grid_dev g, par_bin_args b, par_render_args a,
                                                            uint32_t out_rgba, int n_insert, int2 part) {
+    stamp(g, a.flags, 0, 0);
     if ((int)blockIdx.x < n_insert) {
         bin_insert_body<ENT>(g, b, (int)blockIdx.x, n_insert);
     } else {
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_insert, (int)gridDim.x - n_insert, part);
     }
+    stamp(g, a.flags, 0, 7);
 }
 
 __global__ __launch_bounds__(256) void resolve_fill_kernel(par_grid_dev g, par_bin_args b, par_render_args a,
                                                             uint32_t out_rgba, int n_resolve, int2 part) {
+    stamp(g, a.flags, 1, 0);
     if ((int)blockIdx.x < n_resolve) {
         bin_resolve_body(g, b, (int)blockIdx.x);
     } else {
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_resolve, (int)gridDim.x - n_resolve, part);
     }
+    stamp(g, a.flags, 1, 7);
 }
 
 // Any plane, any geometry: one pixel per thread (parity / debugging planes and odd view sizes).
@@ -969,101 +1017,124 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// render_wave_kernel: the pixels of the occupied columns, wavefront by wavefront (no workgroup cooperation).
-// A column's pixels are cut into 64-pixel chunks -- entry rectangle by entry rectangle (a pixel several entries
-// cover belongs to the FIRST of them in list order, so every covered pixel is rendered exactly once and the lanes of
-// a chunk are nearly all covered pixels), or the whole tile when the rectangles add up to more than the tile
-// (columns_kernel decides) -- and chunk k belongs to wavefront k mod (parts * PAR_WAVE_NW) of the column's
-// workgroups. The launch has gridDim.y workgroups per column; a column uses as many as its work is worth
-// (chunks x entries / cost_per_part), the others leave at once. The record is read where columns_kernel left it:
-// its fields are wave-uniform, so they arrive through the scalar cache; sprite 0's tables come through L1. No
-// LDS, no barrier, nothing to stage: a wavefront's first pixel is three dependent loads away from its start, and
-// the hardware dispatcher balances the columns. What no entry covers keeps the background the fill wrote.
-// (Measured against persistent 5-wavefront workgroups with LDS-staged records and sprite tables, 4096^2 / 1024
-// primitives: 32 instead of 46 us alone, 40 instead of 50 us per frame with three frames in flight.)
+// render_column_generic: a column WITHOUT a usable record (it overflowed one, or PAR_FORCE_GENERIC=1): the whole
+// tile, 64 pixels per wavefront; chunk k belongs to wavefront k mod (max_parts * PAR_WAVE_NW) of the column's
+// workgroups. The primary pass reads the column's bins straight from the hash, as the reference does, and the shadow
+// walks are done in the kernel (render_chunk<true>). Only bx, by of the record are read.
 // ------------------------------------------------------------------------------------------------------------
-template <bool GENERIC>
-__device__ __forceinline__ void render_column(const par_grid_dev& g, const par_render_args& a, int ci, int part,
-                                              int max_parts, int cost_per_part, WaveScratch* ws) {
+__device__ __forceinline__ void render_column_generic(const par_grid_dev& g, const par_render_args& a, int ci,
+                                                      int part, int max_parts, WaveScratch* ws) {
     const int lane = (int)threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const par_colrec& rec_ = g.colrec[ci];
-    const int n_entries_rec = rec_.n_entries, n_nb = rec_.n_nb;
     const int bx = rec_.bx, by = rec_.by;
-    const bool tile_mode = GENERIC || rec_.tile_mode != 0;
-    const uint64_t dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
     ColumnRegs cr;
     cr.ent = make_uint4(0, 0, 0, 0);
     cr.ebz = 0;
     cr.nb = make_uint2(0, 0);
-    if (!GENERIC) {
-        cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
-        cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
-        cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
+    const int n_workers = max_parts * PAR_WAVE_NW, worker = part * PAR_WAVE_NW + wave;
+    const int W = a.W, H = a.H, B = a.B;
+    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+    const int c0 = bx * B;
+    const int rw = min(B, W - c0);
+    const int ry0 = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
+    const int rh = rows_hi - ry0;
+    if (rw <= 0 || rh <= 0) return;
+    const int area = rw * rh;
+    const int n_chunks = (area + 63) >> 6;
+    // floor(p / rw) == __umulhi(p, magic_w) for p * rw < 2^32; a 1-pixel-wide rectangle has no such multiplier
+    const uint32_t magic_w = (uint32_t)(0xFFFFFFFFu / (uint32_t)rw) + 1u;
+    for (int c = worker; c < n_chunks; c += n_workers) {
+        const int pidx = c * 64 + lane;
+        const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
+        const int col = c0 + (pidx - pyy * rw), row = ry0 + pyy;
+        // the chunk's first and last row (wave-uniform)
+        const int p_first = c * 64, p_last = min(p_first + 63, area - 1);
+        const int row_lo = ry0 + ((rw == 1) ? p_first : (int)__umulhi((uint32_t)p_first, magic_w));
+        const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
+        render_chunk<true>(g, a, rec_, cr, 0, dyn, 0, 0, bx, by, -1, col, row, row_lo, row_hi, pidx < area, lane,
+                           ws + wave);
     }
-    if (!GENERIC && rec_.overflow) return;  // render_overflow_kernel's
-    // a column's chunks are shared by as many workgroups as its work is worth (the others of its row leave at once)
-    const int col_parts =
-        GENERIC ? max_parts
-                : min(max_parts, max(1, (rec_.chunks * (n_entries_rec + PAR_WAVE_CHUNK_COST) + cost_per_part - 1) /
-                                            cost_per_part));
-    if (part >= col_parts) return;
-    const int n_workers = col_parts * PAR_WAVE_NW, worker = part * PAR_WAVE_NW + wave;
-    const int n_entries = (GENERIC || (a.flags & (1u << 24))) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
+}
+
+// render_item: one work item = one 64-pixel chunk of one column with a record (columns_kernel listed it), one
+// wavefront. `pass`: the entry whose rectangle is visited (the lanes render the pixels it is the first to cover), or
+// PAR_ITEM_TILE: the whole tile. The record is read where columns_kernel left it: its fields are wave-uniform, so
+// they arrive through the scalar cache; the entry and bin tables sit one element per lane in registers
+// (v_readlane). No LDS, no barrier, no loop over chunks: every wavefront of the launch is a handful of dependent
+// loads long, whatever its column looks like.
+__device__ __forceinline__ void render_item(const par_grid_dev& g, const par_render_args& a, int ci, uint32_t pass,
+                                            int chunk, int lane) {
+    const par_colrec& rec_ = g.colrec[ci];
+    ColumnRegs cr;
+    cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
+    cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
+    cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
+    const int n_entries_rec = rec_.n_entries, n_nb = rec_.n_nb;
+    const int bx = rec_.bx, by = rec_.by;
+    const uint64_t dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
+    if (rec_.overflow) return;  // render_overflow_kernel's
+    const int n_entries = (a.flags & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
     const int W = a.W, H = a.H, B = a.B;
     const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
     const int c0 = bx * B;
     const int tw = min(B, W - c0);
     const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
-    int k = 0;  // chunks of the column so far (wave-uniform)
-    const int n_pass = tile_mode ? 1 : n_entries;
-    for (int q = 0; q < n_pass; q++) {
-        const int own = tile_mode ? -1 : q;
-        if (!tile_mode && ((dup >> q) & 1)) continue;
-        int rx0, rw, ry0, rh;
-        if (tile_mode) {
-            rx0 = c0; rw = tw; ry0 = rows_lo; rh = rows_hi - rows_lo;
-        } else {
-            const par_slot r = slot_of_lane(cr.ent, q);
-            rx0 = max((int)r.px, c0);
-            rw = min(r.px + r.ex, c0 + tw) - rx0;
-            // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
-            ry0 = max(H - (r.py + r.ey + r.pz + r.ez), rows_lo);
-            rh = min(H - (r.py + r.pz), rows_hi) - ry0;
-        }
-        rx0 = __builtin_amdgcn_readfirstlane(rx0);
-        rw = __builtin_amdgcn_readfirstlane(rw);
-        ry0 = __builtin_amdgcn_readfirstlane(ry0);
-        rh = __builtin_amdgcn_readfirstlane(rh);
-        if (rw <= 0 || rh <= 0) continue;
-        const int area = rw * rh;
-        const int n_chunks = (area + 63) >> 6;
-        // this wavefront's first chunk of the rectangle: the smallest c >= 0 with (k + c) % n_workers == worker
-        int c = worker - k % n_workers;
-        if (c < 0) c += n_workers;
-        k += n_chunks;
-        if (c >= n_chunks) continue;
-        // floor(p / rw) == __umulhi(p, magic_w) for p * rw < 2^32; a 1-pixel-wide rectangle has no such multiplier
-        const uint32_t magic_w = (uint32_t)(0xFFFFFFFFu / (uint32_t)rw) + 1u;
-        for (; c < n_chunks; c += n_workers) {
-            const int pidx = c * 64 + lane;
-            const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
-            const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
-            // the chunk's first and last row (wave-uniform)
-            const int p_first = c * 64, p_last = min(p_first + 63, area - 1);
-            const int row_lo = ry0 + ((rw == 1) ? p_first : (int)__umulhi((uint32_t)p_first, magic_w));
-            const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
-            render_chunk<GENERIC>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi,
-                                  pidx < area, lane, ws ? ws + wave : nullptr);
-        }
+    const bool tile_mode = pass == PAR_ITEM_TILE;
+    const int own = tile_mode ? -1 : (int)pass;
+    int rx0, rw, ry0, rh;
+    if (tile_mode) {
+        rx0 = c0; rw = tw; ry0 = rows_lo; rh = rows_hi - rows_lo;
+    } else {
+        const par_slot r = slot_of_lane(cr.ent, own);
+        rx0 = max((int)r.px, c0);
+        rw = min(r.px + r.ex, c0 + tw) - rx0;
+        // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
+        ry0 = max(H - (r.py + r.ey + r.pz + r.ez), rows_lo);
+        rh = min(H - (r.py + r.pz), rows_hi) - ry0;
+    }
+    rx0 = __builtin_amdgcn_readfirstlane(rx0);
+    rw = __builtin_amdgcn_readfirstlane(rw);
+    ry0 = __builtin_amdgcn_readfirstlane(ry0);
+    rh = __builtin_amdgcn_readfirstlane(rh);
+    if (rw <= 0 || rh <= 0) return;
+    const int area = rw * rh;
+    const int p_first = chunk * 64, p_last = min(p_first + 63, area - 1);
+    if (p_first >= area) return;
+    // floor(p / rw) == __umulhi(p, magic_w) for p * rw < 2^32; a 1-pixel-wide rectangle has no such multiplier
+    const uint32_t magic_w = (uint32_t)(0xFFFFFFFFu / (uint32_t)rw) + 1u;
+    const int pidx = p_first + lane;
+    const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
+    const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
+    // the chunk's first and last row (wave-uniform)
+    const int row_lo = ry0 + ((rw == 1) ? p_first : (int)__umulhi((uint32_t)p_first, magic_w));
+    const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
+    render_chunk<false>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, pidx < area,
+                        lane, nullptr);
+}
+
+// Wavefront `w` of `n_waves` (a multiple of PAR_ITEM_SHARDS): items w / shards, + n_waves / shards, ... of shard
+// w mod shards. The launch offers one wavefront per item of the host's bound, so the loop normally runs once.
+__device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
+    const int lane = (int)threadIdx.x & 63;
+    const int shard = w & (PAR_ITEM_SHARDS - 1);
+    const uint2* list = g.items + (size_t)shard * g.item_capacity;
+    const int first = w >> PAR_ITEM_SHARD_BITS;
+    // the first item is fetched beside the counter (the list is allocated whatever the counter says)
+    uint2 it = list[min(first, g.item_capacity - 1)];
+    const int n = min(g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], g.item_capacity);
+    for (int i = first; i < n;) {
+        if (it.x != PAR_ITEM_NONE) render_item(g, a, (int)it.x, it.y >> 16, (int)(it.y & 0xFFFFu), lane);
+        i += n_waves >> PAR_ITEM_SHARD_BITS;
+        if (i < n) it = list[i];
     }
 }
 
-__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_wave_kernel(par_grid_dev g, par_render_args a,
-                                                                          int cost_per_part) {
-    const int ci = (int)blockIdx.x;
-    if (ci >= g.counters[PAR_CNT_COLS] || ci >= g.col_capacity) return;
-    render_column<false>(g, a, ci, (int)blockIdx.y, (int)gridDim.y, cost_per_part, nullptr);
+__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid_dev g, par_render_args a) {
+    stamp(g, a.flags, 3, 0);
+    const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
+    render_items(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
+    stamp(g, a.flags, 3, 7);
 }
 
 // The columns that overflowed their record (columns_kernel lists them), or every column when a.dense
@@ -1072,38 +1143,38 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_wave_kernel(par_grid_
 // small and its workgroups leave at once when the list is empty.
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_overflow_kernel(par_grid_dev g, par_render_args a) {
     __shared__ WaveScratch scratch[PAR_WAVE_NW];
+    stamp(g, a.flags, 4, 0);
     const int n_cols = min(g.counters[PAR_CNT_COLS], g.col_capacity);
     if (a.dense) {
         for (int ci = (int)blockIdx.x; ci < n_cols; ci += (int)gridDim.x) {
-            render_column<true>(g, a, ci, (int)blockIdx.y, (int)gridDim.y, 1, scratch);
+            render_column_generic(g, a, ci, (int)blockIdx.y, (int)gridDim.y, scratch);
         }
     } else {
         const int n_slow = g.counters[PAR_CNT_SLOW];
         for (int s = (int)blockIdx.x; s < n_slow; s += (int)gridDim.x) {
-            render_column<true>(g, a, g.slow_list[s], (int)blockIdx.y, (int)gridDim.y, 1, scratch);
+            render_column_generic(g, a, g.slow_list[s], (int)blockIdx.y, (int)gridDim.y, scratch);
         }
     }
+    stamp(g, a.flags, 4, 7);
 }
 
 // Both of the above in one launch, for small frames: there a frame is bound by its launches (the host enqueues one
 // in about 3 us, the device needs about 1.5 us between two), not by the registers the overflow path costs the others.
-// Workgroups [0, n_cols_x * parts) render the columns with a record, the rest (groups of `over_parts`) the overflow list.
+// Workgroups [0, n_item_wgs) render the work items, the rest (groups of `over_parts`) the overflow list.
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_dev g, par_render_args a,
-                                                                          int cost_per_part, int n_cols_x, int parts,
-                                                                          int over_parts) {
+                                                                          int n_item_wgs, int over_parts) {
     __shared__ WaveScratch scratch[PAR_WAVE_NW];
     const int b = (int)blockIdx.x;
-    if (b < n_cols_x * parts) {
-        const int ci = b % n_cols_x;
-        if (ci >= g.counters[PAR_CNT_COLS] || ci >= g.col_capacity) return;
-        render_column<false>(g, a, ci, b / n_cols_x, parts, cost_per_part, nullptr);
+    if (b < n_item_wgs) {
+        const int w = __builtin_amdgcn_readfirstlane(b * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
+        render_items(g, a, w, n_item_wgs * PAR_WAVE_NW);
         return;
     }
-    const int j = b - n_cols_x * parts;
-    const int stride = ((int)gridDim.x - n_cols_x * parts) / over_parts;
+    const int j = b - n_item_wgs;
+    const int stride = ((int)gridDim.x - n_item_wgs) / over_parts;
     const int n_slow = g.counters[PAR_CNT_SLOW];
     for (int s = j / over_parts; s < n_slow; s += stride) {
-        render_column<true>(g, a, g.slow_list[s], j % over_parts, over_parts, 1, scratch);
+        render_column_generic(g, a, g.slow_list[s], j % over_parts, over_parts, scratch);
     }
 }
 
@@ -1250,39 +1321,37 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
     return hipSuccess;
 }
 
-hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+// One wavefront per work item of the host's bound (rounded up to whole workgroups and to a multiple of the shard
+// count, which render_items' item-to-wavefront mapping needs).
+static int64_t item_workgroups(int64_t item_bound) {
+    const int64_t unit = PAR_ITEM_SHARDS > PAR_WAVE_NW ? PAR_ITEM_SHARDS : PAR_WAVE_NW;
+    int64_t waves = (item_bound + unit - 1) / unit * unit;
+    if (waves < unit) waves = unit;
+    if (waves > (int64_t)1 << 24) waves = (int64_t)1 << 24;  // (the wavefronts then loop over their shard)
+    return waves / PAR_WAVE_NW;
+}
+
+hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
                              hipStream_t stream) {
-    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
-    const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
-    if (bound <= 0) return hipSuccess;
-    // gridDim.y workgroups (of PAR_WAVE_NW = 2 wavefronts) per column; a column uses as many as its work is worth.
-    // Few columns: more of them, and finer parts, so that a small frame still spreads over the chip.
-    // Fewer wavefronts per column trade one frame's latency for throughput. Measured at 4096^2 / 1024 primitives
-    // (four frames in flight / one frame at a time), wavefronts per workgroup x workgroups per column, cost per part:
-    // 4 x 2, 100: 30.0 / 57.3 us   2 x 2, 100: 27.9 / 62.7   2 x 3, 50: 29.3 / 58.3   2 x 4, 50: 30.2 / 56.4
-    // 1 x 4, 50: 27.3 / 62.6   1 x 2, 100: 31.6 / 78.7   8 x 2, 100: 39.2 / 60.4. The benchmark is a rate: 2 x 2.
-    const int parts = bound >= 2048 ? 2 : (bound >= 512 ? 8 : 16);
-    const int cost_per_part = bound >= 2048 ? 100 : (bound >= 512 ? 25 : 12);
-    if (a.dense) return hipSuccess;
-    hipLaunchKernelGGL(render_wave_kernel, dim3((unsigned)bound, (unsigned)parts), dim3(PAR_WAVE_NW * 64), 0, stream, g,
-                       a, cost_per_part);
+    if (item_bound <= 0 || a.dense) return hipSuccess;
+    hipLaunchKernelGGL(render_items_kernel, dim3((unsigned)item_workgroups(item_bound)), dim3(PAR_WAVE_NW * 64), 0,
+                       stream, g, a);
     return hipGetLastError();
 }
 
-// Small frames: columns with a record and overflowed columns in one launch. hipErrorNotSupported (nothing launched)
-// for large frames, where the two kernels' different register needs matter.
+// Small frames: work items and overflowed columns in one launch. hipErrorNotSupported (nothing launched) for large
+// frames, where the two kernels' different register needs matter.
 hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
-                                  hipStream_t stream) {
+                                  int64_t item_bound, hipStream_t stream) {
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound >= 2048 || a.dense) return hipErrorNotSupported;
     if (bound <= 0) return hipSuccess;
-    const int parts = bound >= 512 ? 8 : 16;  // (of PAR_WAVE_NW = 2 wavefronts, as in par_launch_render)
-    const int cost_per_part = bound >= 512 ? 25 : 12;
     const int over_parts = 8;
     const int64_t over_cols = bound < 32 ? bound : 32;
-    hipLaunchKernelGGL(render_both_kernel, dim3((unsigned)(bound * parts + over_cols * over_parts)),
-                       dim3(PAR_WAVE_NW * 64), 0, stream, g, a, cost_per_part, (int)bound, parts, over_parts);
+    const int64_t n_item_wgs = item_workgroups(item_bound);
+    hipLaunchKernelGGL(render_both_kernel, dim3((unsigned)(n_item_wgs + over_cols * over_parts)),
+                       dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs, over_parts);
     return hipGetLastError();
 }
 

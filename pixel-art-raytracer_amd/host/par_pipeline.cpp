@@ -5,7 +5,12 @@
 // with par_update_aabbs_async. The reference's host is C++, so this is the loop a maintainer would write; it also
 // shows the frame rate without an interpreter in the submit path.
 //
-//   par_pipeline [--size S] [--prims N] [--frames F] [--inflight K] [--moving] [--check]
+//   par_pipeline [--size S] [--prims N] [--frames F] [--inflight K] [--moving] [--check] [--flags X] [--stamps F0]
+//
+// --flags X: render flags for every frame (the timing-experiment bits of par_raytracer.h; the output is then wrong).
+// --stamps F0 (with PAR_DEBUG_STAMPS=1 in the environment): the K frames from F0 on note the GPU's 100 MHz clock at
+// every workgroup's start and end; afterwards the span of each of their kernels is printed (a timeline of the
+// frames in flight without a profiler in the way).
 //
 // --check renders the last K frames once more through the blocking host path (par_render) and compares.
 // HIP streams share a few hardware queues, and two streams on one queue do not overlap: the streams are picked by a
@@ -21,6 +26,9 @@
 #include <vector>
 
 #include "par_raytracer.h"
+
+// internal profiling aid of the library (not in the public header)
+extern "C" int par_debug_read_stamps(par_context* ctx, unsigned long long* out, size_t count);
 
 #define HIP_OK(x)                                                                        \
     do {                                                                                 \
@@ -54,6 +62,8 @@ static double now_s() {
 int main(int argc, char** argv) {
     int size = 4096, prims = 1024, frames = 2000, inflight = 4;
     bool moving = false, check = false;
+    int stamps_from = -1;
+    unsigned all_flags = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&](int& v) { if (i + 1 < argc) v = std::atoi(argv[++i]); };
@@ -63,6 +73,8 @@ int main(int argc, char** argv) {
         else if (a == "--inflight") next(inflight);
         else if (a == "--moving") moving = true;
         else if (a == "--check") check = true;
+        else if (a == "--stamps") next(stamps_from);
+        else if (a == "--flags") { int v = 0; next(v); all_flags = (unsigned)v; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (inflight < 1 || inflight > 16 || frames < 1) return 2;
@@ -136,7 +148,8 @@ int main(int argc, char** argv) {
             scene_of(f, cur);
             PAR_OK_(s.ctx, par_update_aabbs_async(s.ctx, cur.data(), 0, prims, s.stream));
         }
-        PAR_OK_(s.ctx, par_render_device(s.ctx, s.stream, 0, H, &s.out, 0));
+        const unsigned fl = all_flags | ((stamps_from >= 0 && f >= stamps_from && f < stamps_from + inflight) ? (1u << 29) : 0u);
+        PAR_OK_(s.ctx, par_render_device(s.ctx, s.stream, 0, H, &s.out, fl));
         return 0;
     };
     const int warm = std::min(frames, 200);
@@ -144,12 +157,50 @@ int main(int argc, char** argv) {
     HIP_OK(hipDeviceSynchronize());
     const double t0 = now_s();
     for (int f = 0; f < frames; f++) if (submit(f)) return 1;
+    const double t_enq = now_s() - t0;  // the host's share: time until the last frame was enqueued
     HIP_OK(hipDeviceSynchronize());
     const double dt = now_s() - t0;
     std::printf("{\"host\": \"C++\", \"size\": %d, \"prims\": %d, \"moving\": %s, \"frames\": %d, \"inflight\": %d, "
-                "\"us_per_frame\": %.2f, \"frames_per_s\": %.0f, \"mrays_per_s\": %.0f}\n",
-                size, prims, moving ? "true" : "false", frames, inflight, 1e6 * dt / frames, frames / dt,
-                2.0 * W * H * frames / dt / 1e6);
+                "\"us_per_frame\": %.2f, \"host_enqueue_us_per_frame\": %.2f, \"frames_per_s\": %.0f, "
+                "\"mrays_per_s\": %.0f}\n",
+                size, prims, moving ? "true" : "false", frames, inflight, 1e6 * dt / frames, 1e6 * t_enq / frames,
+                frames / dt, 2.0 * W * H * frames / dt / 1e6);
+
+    if (stamps_from >= 0) {
+        // rows: the frame's kernels; per workgroup 8 slots, slot 0 = start, slot 7 = end (100 MHz ticks)
+        static const char* names[5] = {"insert+fill", "resolve+fill", "columns+fill", "render_items", "render_overflow"};
+        const size_t rows = 5, wgs = 8192, n = rows * wgs * 8;
+        std::vector<std::vector<unsigned long long>> st(slots.size(), std::vector<unsigned long long>(n));
+        unsigned long long t_min = ~0ull;
+        for (size_t k = 0; k < slots.size(); k++) {
+            if (par_debug_read_stamps(slots[k].ctx, st[k].data(), n) != PAR_OK) {
+                std::fprintf(stderr, "no stamps: run with PAR_DEBUG_STAMPS=1\n");
+                return 1;
+            }
+            for (size_t i = 0; i < rows * wgs; i++) {
+                if (st[k][i * 8]) t_min = std::min(t_min, st[k][i * 8]);
+            }
+        }
+        for (size_t k = 0; k < slots.size(); k++) {
+            const int f = stamps_from + (int)((k + slots.size() - (size_t)stamps_from % slots.size()) % slots.size());
+            for (size_t r = 0; r < rows; r++) {
+                unsigned long long a0 = ~0ull, a1 = 0, last_start = 0;
+                size_t cnt = 0;
+                for (size_t i = 0; i < wgs; i++) {
+                    const unsigned long long b = st[k][(r * wgs + i) * 8], e = st[k][(r * wgs + i) * 8 + 7];
+                    if (!b) continue;
+                    cnt++;
+                    a0 = std::min(a0, b);
+                    last_start = std::max(last_start, b);
+                    a1 = std::max(a1, std::max(b, e));
+                }
+                if (!cnt) continue;
+                std::printf("stamps frame %d slot %zu %-16s start %8.2f  last-wg-start %8.2f  end %8.2f  (%.2f us, %zu wgs)\n",
+                            f, k, names[r], (a0 - t_min) * 0.01, (last_start - t_min) * 0.01, (a1 - t_min) * 0.01,
+                            (a1 - a0) * 0.01, cnt);
+            }
+        }
+    }
 
     int bad = 0;
     if (check) {

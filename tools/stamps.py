@@ -17,16 +17,34 @@ ptrs = {"fb": fb.data_ptr(), "palidx": pal.data_ptr()}
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(20):
     r.render_device(ptrs, stream=s)
+r.render_device(ptrs, stream=s, flags=1 << 29)  # the stamped frame
 torch.cuda.synchronize()
-n = 2 * 8192 * 8
+n = 5 * 8192 * 8
 buf = np.zeros(n, dtype=np.uint64)
 L_ = par.lib()
 L_.par_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = L_.par_debug_read_stamps(r._ctx, buf.ctypes.data_as(C.c_void_p), n)
 assert rc == 0, rc
-st = buf.reshape(2, 8192, 8).astype(np.float64) * 0.01  # us (100 MHz)
-for k, name, labels in ((0, "columns_body", ["start", "listed", "A done", "B walks done", "end"]),):
-    x = st[k]
+st = buf.reshape(5, 8192, 8).astype(np.float64) * 0.01  # us (100 MHz)
+ncol = int(r.stats().occupied_columns)
+for row, name in enumerate(["insert+fill", "resolve+fill", "columns+fill", "render_items", "render_overflow"]):
+    x = st[row]
+    live = x[:, 0] > 0
+    if not live.any():
+        continue
+    b, e = x[live, 0], np.maximum(x[live, 7], x[live, 0])
+    t0 = b.min()
+    d = e - b
+    print(f"{name:16s}: {live.sum():5d} workgroups; starts 0 .. {b.max()-t0:6.2f} us (median {np.median(b)-t0:5.2f}); "
+          f"kernel span {e.max()-t0:6.2f} us; workgroup life median {np.median(d):5.2f} p90 {np.percentile(d,90):5.2f} "
+          f"max {d.max():5.2f} us")
+    if row == 2:
+        idx = np.nonzero(live)[0]
+        fill = idx >= idx.max() - 255
+        print(f"    fill workgroups (last 256): life median {np.median(d[fill]):5.2f} max {d[fill].max():5.2f}; end of the "
+              f"last one {e[fill].max()-t0:6.2f}; end of the last column workgroup {e[~fill].max()-t0:6.2f} us")
+for k, name, labels in ((2, "columns_body", ["start", "listed", "A done", "B walks done", "end"]),):
+    x = st[k][:ncol]
     live = x[:, 4] > 0
     x = x[live]
     t0 = x[:, 0].min()
