@@ -26,6 +26,8 @@ struct par_context {
     std::vector<int32_t> h_cols;   // screen columns (bx, by) each entity reaches: its pairs without the z factor
     int64_t total_cols = 0;        // >= the occupied columns of the frame
     int64_t total_items = 0;       // >= the render work items (64-pixel chunks) of the frame, see items_of
+    std::vector<int32_t> h_colpairs;  // (entity, bin) pairs per screen column (>= its occupied bins, >= its entries)
+    int64_t cols_over = 0;            // columns with more pairs than a column record is sure to hold
     int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
     bool have_light = false, have_entities = false;
     par_light light{};
@@ -106,6 +108,32 @@ int64_t pairs_of(const par_context* c, const par_aabb& a, int32_t* cols = nullpt
     if (x1 <= x0 || y1 <= y0 || z1 <= z0) return 0;
     if (cols) *cols = (x1 - x0) * (y1 - y0);
     return (int64_t)(x1 - x0) * (y1 - y0) * (z1 - z0);
+}
+
+// Adds (sign = +1) or removes (-1) an AABB's pairs in the per-column histogram. A column whose pairs exceed
+// PAR_COL_NB (<= PAR_COL_ENT) may overflow its record; while there is none, no column can, and the frame needs no
+// launch for the overflow list.
+void col_hist(par_context* c, const par_aabb& a, int sign) {
+    const int W = c->params.width, H = c->params.height, L = c->params.length, B = c->params.bin_size;
+    const int minx = a.px, miny = a.py, minz = a.pz;
+    const int maxx = minx + a.ex, maxy = miny + a.ey, maxz = minz + a.ez;
+    if ((maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) || (maxz < -a.ez - B) ||
+        (minz > L + B)) {
+        return;
+    }
+    const int x0 = std::max(0, minx / B), y0 = std::max(0, (H - maxy - maxz) / B), z0 = std::max(0, minz / B);
+    const int x1 = std::min(c->gx, (maxx + B - 1) / B), y1 = std::min(c->gy, (H - miny - minz + B - 1) / B);
+    const int z1 = std::min(c->gz, (maxz + B - 1) / B);
+    if (x1 <= x0 || y1 <= y0 || z1 <= z0) return;
+    constexpr int kSure = PAR_COL_NB < PAR_COL_ENT ? PAR_COL_NB : PAR_COL_ENT;
+    for (int x = x0; x < x1; x++) {
+        for (int y = y0; y < y1; y++) {
+            int32_t& n = c->h_colpairs[(size_t)x * c->gy + y];
+            const bool was = n > kSure;
+            n += sign * (z1 - z0);
+            c->cols_over += (int)(n > kSure) - (int)was;
+        }
+    }
 }
 
 bool extent_ok(const par_aabb& a) {
@@ -313,11 +341,20 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     const bool ride = !ev && !no_fill && par_plan_fill(r, &plan);
     par_render_args rf = r;  // what rides along: the frame and palette-index planes
     rf.out.lit = nullptr;
-    PAR_HIP(par_launch_bin_insert(ctx->grid, b, &rf, ride ? &plan : nullptr, stream));
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
     // what par_graph_stage accepts (graph_pair_bound); beyond it the caller captures again.
     const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : ctx->total_pairs;
-    PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, &rf, ride ? &plan : nullptr, stream));
+    // small scenes build the hash in one launch, large ones in two (timed runs keep the kernels apart)
+    static const bool two_env = [] { const char* e = std::getenv("PAR_BUILD_TWO_LAUNCHES"); return e && e[0] == '1'; }();
+    const bool two_launches = two_env || (flags & (1u << 23));  // bit 23 (tests): insert and resolve as two launches
+    hipError_t be = (ev || two_launches) ? hipErrorNotSupported
+                                         : par_launch_build(ctx->grid, b, pair_bound, &rf, ride ? &plan : nullptr, stream);
+    if (be == hipErrorNotSupported) {
+        PAR_HIP(par_launch_bin_insert(ctx->grid, b, &rf, ride ? &plan : nullptr, stream));
+        PAR_HIP(par_launch_bin_resolve(ctx->grid, b, pair_bound, &rf, ride ? &plan : nullptr, stream));
+    } else if (be != hipSuccess) {
+        return hip_fail(ctx, be, "par_launch_build");
+    }
     // occupied columns <= the columns the entities reach one by one (<= their (entity, bin) pairs)
     const int64_t col_bound = graph_mode ? pair_bound : ctx->total_cols;
     if (ride) {
@@ -343,9 +380,12 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // work items <= what the entities can cause one by one, and <= every column of the rendered rows as a whole tile
     const int64_t item_cap_rows = max_items(ctx) / ctx->gy * (r.by_hi - r.by_lo + 1);
     const int64_t item_bound = std::min(graph_mode ? ctx->graph_item_bound : ctx->total_items, item_cap_rows);
+    // The overflow list is empty for sure while no column has more pairs than a record holds (a captured graph also
+    // serves later frames, whose columns nobody knows yet).
+    const bool may_overflow = graph_mode || ctx->cols_over > 0 || r.dense || ev;
     bool both = false;
     if (!ev) {  // small frames: one launch for both render kernels
-        const hipError_t e = par_launch_render_both(ctx->grid, r, col_bound, item_bound, stream);
+        const hipError_t e = par_launch_render_both(ctx->grid, r, col_bound, item_bound, may_overflow, stream);
         if (e == hipSuccess) {
             both = true;
         } else if (e != hipErrorNotSupported) {
@@ -354,7 +394,7 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     }
     if (!both) PAR_HIP(par_launch_render(ctx->grid, r, item_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[4], stream));
-    if (!both) PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
+    if (!both && may_overflow) PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
     return PAR_OK;
 }
@@ -454,6 +494,8 @@ int par_create(const par_params* params, int device, par_context** out) {
     }
     if ((e = hipMalloc(&ctx->grid.col_list, (size_t)gx * gy * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMalloc(&ctx->grid.counters, PAR_CNT_TOTAL * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMalloc(&ctx->grid.build_sync, 64 * sizeof(int32_t))) != hipSuccess) return bail(e);
+    if ((e = hipMemset(ctx->grid.build_sync, 0, 64 * sizeof(int32_t))) != hipSuccess) return bail(e);
     {
         const size_t bytes = (size_t)PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE * sizeof(int32_t);
         if ((e = hipMalloc(&ctx->grid.item_counters, bytes)) != hipSuccess) return bail(e);
@@ -502,7 +544,7 @@ void par_destroy(par_context* ctx) {
         if (ctx->grid.colflag[s]) (void)hipFree(ctx->grid.colflag[s]);
     }
     void* lists[] = {ctx->grid.col_list, ctx->grid.counters, ctx->grid.slow_list, ctx->grid.stamps, ctx->grid.bgwalk,
-                     ctx->grid.bglit, ctx->d_scratch_lit, ctx->grid.items, ctx->grid.item_counters};
+                     ctx->grid.bglit, ctx->d_scratch_lit, ctx->grid.items, ctx->grid.item_counters, ctx->grid.build_sync};
     for (void* p : lists) {
         if (p) (void)hipFree(p);
     }
@@ -604,6 +646,9 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
         PAR_HIP(hipMemcpy(ctx->d_sprite_ids, sprite_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     ctx->h_aabbs.assign(aabbs, aabbs + n);
+    ctx->h_colpairs.assign((size_t)ctx->gx * ctx->gy, 0);
+    ctx->cols_over = 0;
+    for (int i = 0; i < n; i++) col_hist(ctx, aabbs[i], +1);
     ctx->h_pairs.swap(pairs);
     ctx->total_pairs = total;
     ctx->h_cols.swap(cols);
@@ -672,6 +717,8 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
     PAR_HIP(hipMemcpyAsync(ctx->d_aabbs + first, aabbs, (size_t)n * sizeof(par_aabb), hipMemcpyHostToDevice, ctx->stream));
     PAR_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n; i++) {
+        col_hist(ctx, ctx->h_aabbs[(size_t)(first + i)], -1);
+        col_hist(ctx, aabbs[i], +1);
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
         ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
@@ -727,6 +774,8 @@ int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, i
     ctx->ev_update_pending = true;
     ctx->update_stream = stream;
     for (int i = 0; i < n; i++) {
+        col_hist(ctx, ctx->h_aabbs[(size_t)(first + i)], -1);
+        col_hist(ctx, aabbs[i], +1);
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
         ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
@@ -859,6 +908,8 @@ int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, c
                             items_of(ctx->h_aabbs[(size_t)(first + i)], ctx->h_cols[(size_t)(first + i)]);
         ctx->total_cols += nc - ctx->h_cols[(size_t)(first + i)];
         ctx->h_cols[(size_t)(first + i)] = nc;
+        col_hist(ctx, ctx->h_aabbs[(size_t)(first + i)], -1);
+        col_hist(ctx, aabbs[i], +1);
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->pin_aabbs[first + i] = aabbs[i];
     }

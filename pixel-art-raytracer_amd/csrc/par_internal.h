@@ -24,8 +24,8 @@ constexpr int PAR_STAMP_ROWS = 5;       // kernels of a frame
 // Kernel geometry (see DESIGN.md "kernels").
 constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count (bin coordinates are kept in int16)
 // Per-column record built once per frame by columns_kernel and consumed by every wavefront rendering the column.
-constexpr int PAR_COL_NB = 16;          // occupied bins of one column it can describe
-constexpr int PAR_COL_ENT = 48;         // slot records of one column
+constexpr int PAR_COL_NB = 32;          // occupied bins of one column it can describe
+constexpr int PAR_COL_ENT = 64;         // slot records of one column (one per lane of the rendering wavefront)
 constexpr int PAR_BIN_WALK = 64;        // occluder records of one start bin's shadow walk
 constexpr int PAR_COL_WALK = 160;       // occluder records of all walks of one column
 constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = 160;  // supported bin sizes
@@ -42,7 +42,7 @@ static_assert(sizeof(par_texel) == 16, "texel record must stay 16 bytes");
 struct par_colrec_nb {
     int16_t bz;          // bin_z of an occupied bin of the column, ascending
     uint8_t off, cnt;    // its records: entries[off, off+cnt)
-    int16_t woff, wcnt;  // the shadow walk that starts in it: walk[woff, woff+wcnt)
+    int16_t woff, wcnt;  // the shadow walk that starts in it: walk[woff, woff+wcnt); wcnt -1: not recorded (too long)
 };
 struct par_colrec {
     int16_t n_nb, n_entries, n_walk;
@@ -93,6 +93,7 @@ struct par_grid_dev {
     par_colrec* colrec;       // [col_capacity] indexed like col_list
     uint2* items;             // [PAR_ITEM_SHARDS * item_capacity] render work items: one 64-pixel chunk each
     int32_t* item_counters;   // [PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE] items per shard (reset by insert)
+    int32_t* build_sync;      // [64] barrier words of build_fill_kernel (arrived, left; they reset themselves)
     int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
     par_bgwalk* bgwalk;       // [gx] shadow walks of the background rays (traced only on request)
     uint8_t* bglit;           // [width] result of the background ray of screen column x
@@ -145,7 +146,7 @@ constexpr int PAR_ITEM_SHARDS = 1 << PAR_ITEM_SHARD_BITS;
 constexpr int PAR_ITEM_COUNTER_STRIDE = 32;  // int32 words between two shard counters: one 128-byte line each
 constexpr uint32_t PAR_ITEM_TILE = 0xFFFFu;
 constexpr uint32_t PAR_ITEM_NONE = 0xFFFFFFFFu;  // a reserved item slot whose column went to the overflow list
-enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_TOTAL = 8 };
+enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_ERROR = 2, PAR_CNT_TOTAL = 8 };
 
 // The background fill split over the frame's first three launches: 512-pixel chunks [cut[i], cut[i+1]) go with
 // launch i (hash insert, hash resolve, column records).
@@ -160,6 +161,9 @@ bool par_plan_fill(const par_render_args& a, par_fill_plan* plan);
 // `fill` (nullable, with the render args `fa`): this launch also carries its share of the fill.
 hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, const par_render_args* fa,
                                  const par_fill_plan* fill, hipStream_t stream);
+// Both of the above in one launch for small scenes (else hipErrorNotSupported, nothing launched).
+hipError_t par_launch_build(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, const par_render_args* fa,
+                            const par_fill_plan* fill, hipStream_t stream);
 hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound,
                                   const par_render_args* fa, const par_fill_plan* fill, hipStream_t stream);
 // Per occupied column: compact slot list + the shadow walks of its bins (+ the background walks when a.trace_bg);
@@ -176,7 +180,7 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
                              hipStream_t stream);
 // Both render kernels in one launch for small frames (else hipErrorNotSupported, nothing launched).
 hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
-                                  int64_t item_bound, hipStream_t stream);
+                                  int64_t item_bound, bool may_overflow, hipStream_t stream);
 // The columns that overflowed their record (every column when a.dense).
 hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                       hipStream_t stream);

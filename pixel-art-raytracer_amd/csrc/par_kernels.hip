@@ -41,6 +41,20 @@ __device__ __forceinline__ int flat_index(int gy, int gz, int x, int y, int z) {
     return x * gy * gz + y * gz + z;  // index_into_view_hash alt:180-182
 }
 
+// Device-coherent accesses for data handed from one workgroup to another INSIDE a launch (build_fill_kernel): the
+// L2s of the XCDs are not coherent with each other, so such stores write through (sc1) and such loads miss in L2.
+// COH = false: plain accesses (the hand-over is a kernel boundary).
+template <bool COH, typename T>
+__device__ __forceinline__ void st_shared(T* p, T v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool COH, typename T>
+__device__ __forceinline__ T ld_shared(const T* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -66,7 +80,7 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 // large ones so that the node counter sees one atomic per 64 entities). Lane l < ENT culls and sizes entity l; the
 // wavefront reserves its nodes with ONE atomic; then all 64 lanes walk the (entity, bin) pairs side by side, so the
 // list-head exchanges of a wavefront are in flight together instead of one after the other.
-template <int ENT>
+template <int ENT, bool COH = false>
 __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par_bin_args& a, int block, int n_blocks) {
     const int tid = block * blockDim.x + threadIdx.x;
     const int stride = n_blocks * blockDim.x;
@@ -80,7 +94,9 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
         g.count[o][b] = 0;
         g.colflag[o][b / g.gz] = 0;
     }
-    if (tid < PAR_CNT_TOTAL) g.counters[tid] = 0;
+    // (resolve adds to the column counter with atomics: in the one-launch build a plain zero written here could
+    // reach memory after them)
+    if (tid < PAR_CNT_TOTAL) st_shared<COH>(&g.counters[tid], 0);
     if (tid < PAR_ITEM_SHARDS) g.item_counters[tid * PAR_ITEM_COUNTER_STRIDE] = 0;
 
     const int W = a.W, H = a.H, L = a.L, B = a.B;
@@ -135,9 +151,9 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
                 const int node = base + p;
                 // the host sizes the pool from the exact pair count and b is in range by construction: belt and braces
                 if (node < g.capacity && b >= 0 && b < g.volume) {
-                    g.node_entity[s][node] = e0 + lo;
-                    g.node_bin[s][node] = b;
-                    g.node_next[s][node] = atomicExch(&g.head[s][b], node + 1);
+                    st_shared<COH>(&g.node_entity[s][node], e0 + lo);
+                    st_shared<COH>(&g.node_bin[s][node], b);
+                    st_shared<COH>(&g.node_next[s][node], atomicExch(&g.head[s][b], node + 1));
                 }
             }
         }
@@ -151,20 +167,30 @@ __global__ __launch_bounds__(256) void bin_insert_kernel(par_grid_dev g, par_bin
     stamp(g, a.flags, 0, 7);
 }
 
-__device__ __forceinline__ void bin_resolve_body(const par_grid_dev& g, const par_bin_args& a, int block) {
-    const int tid = block * blockDim.x + threadIdx.x;
+// `tid` of `n_threads` (one thread per node, or a grid-stride loop over the nodes when the launch is smaller).
+template <bool COH>
+__device__ __forceinline__ void bin_resolve_node(const par_grid_dev& g, const par_bin_args& a, int tid);
+
+template <bool COH = false>
+__device__ __forceinline__ void bin_resolve_body(const par_grid_dev& g, const par_bin_args& a, int block, int n_blocks) {
+    const int tid0 = block * blockDim.x + threadIdx.x;
     const int s = a.set;
-    // insert (the previous kernel) has consumed the other set's counter: free it for the next frame's inserts
-    if (tid == 0) g.node_counter[s ^ 1] = 0;
-    const int n_nodes = min(g.node_counter[s], g.capacity);
-    if (tid >= n_nodes) return;
-    const int b = g.node_bin[s][tid];
-    if (g.head[s][b] != tid + 1) return;  // only the most recent insertion resolves its bin
+    // insert has consumed the other set's counter: free it for the next frame's inserts
+    if (tid0 == 0) g.node_counter[s ^ 1] = 0;
+    const int n_nodes = min(ld_shared<COH>(&g.node_counter[s]), g.capacity);
+    for (int tid = tid0; tid < n_nodes; tid += n_blocks * blockDim.x) bin_resolve_node<COH>(g, a, tid);
+}
+
+template <bool COH>
+__device__ __forceinline__ void bin_resolve_node(const par_grid_dev& g, const par_bin_args& a, int tid) {
+    const int s = a.set;
+    const int b = ld_shared<COH>(&g.node_bin[s][tid]);
+    if (ld_shared<COH>(&g.head[s][b]) != tid + 1) return;  // only the most recent insertion resolves its bin
 
     int top0 = -1, top1 = -1, top2 = -1, top3 = -1, top4 = -1, top5 = -1, top6 = -1;  // 7 largest, descending
     int k = 0;
-    for (int cur = tid + 1; cur != 0; cur = g.node_next[s][cur - 1]) {
-        int e = g.node_entity[s][cur - 1];
+    for (int cur = tid + 1; cur != 0; cur = ld_shared<COH>(&g.node_next[s][cur - 1])) {
+        int e = ld_shared<COH>(&g.node_entity[s][cur - 1]);
         int t;
         // bubble the new index through the sorted registers (static indexing keeps them out of scratch)
         if (e > top0) { t = top0; top0 = e; e = t; }
@@ -211,7 +237,7 @@ __device__ __forceinline__ void bin_resolve_body(const par_grid_dev& g, const pa
 
 __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bin_args a) {
     stamp(g, a.flags, 1, 0);
-    bin_resolve_body(g, a, (int)blockIdx.x);
+    bin_resolve_body(g, a, (int)blockIdx.x, (int)gridDim.x);
     stamp(g, a.flags, 1, 7);
 }
 
@@ -505,7 +531,13 @@ __device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_re
             if (lane == 0 && !w_over) woff = atomicAdd(&sm.n_walk, n_rec);
             woff = __shfl(woff, 0);
             if (w_over || woff + n_rec > PAR_COL_WALK) {
-                if (lane == 0) sm.overflow = 1;
+                // more occluders on the way than the record holds: the pixels that start here walk for themselves
+                // (lane_shadow_walk in the render kernel), the column keeps its record
+                if (lane == 0) {
+                    if (!w_over) atomicSub(&sm.n_walk, n_rec);
+                    sm.nb[i].woff = 0;
+                    sm.nb[i].wcnt = -1;
+                }
             } else {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -705,11 +737,63 @@ __global__ __launch_bounds__(256) void resolve_fill_kernel(par_grid_dev g, par_b
                                                             uint32_t out_rgba, int n_resolve, int2 part) {
     stamp(g, a.flags, 1, 0);
     if ((int)blockIdx.x < n_resolve) {
-        bin_resolve_body(g, b, (int)blockIdx.x);
+        bin_resolve_body(g, b, (int)blockIdx.x, n_resolve);
     } else {
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_resolve, (int)gridDim.x - n_resolve, part);
     }
     stamp(g, a.flags, 1, 7);
+}
+
+// Small scenes: the whole hash build in ONE launch. The first `n_build` workgroups insert, meet at a barrier of their
+// own (they are few and the first of the grid, so they are resident together whatever else runs), and resolve; the
+// others carry the fill shares of both launches this replaces. A kernel boundary costs the frame's launch chain about
+// 2 us on the device and the host a launch (about 4 us); the barrier costs less than either.
+// The barrier: what insert hands to resolve is stored write-through and loaded past the L2 (the L2s of the XCDs
+// are not coherent with each other; a device-scope release fence instead would write back every dirty line of the
+// L2, the fill's included: measured 14 us for this kernel). Every thread waits for its stores, one thread per
+// workgroup arrives on a counter and waits for the others; the last workgroup to leave resets the counters for the
+// next frame. The wait is bounded (a lost workgroup must not hang the GPU): should it
+// ever expire, the frame is wrong and g.counters[PAR_CNT_ERROR] says so.
+__device__ __forceinline__ void build_barrier(const par_grid_dev& g, int n_build) {
+    // every store of this thread has completed (the hand-over stores write through, st_shared)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t* arrived = g.build_sync;
+        int32_t* left = g.build_sync + 32;  // (a cache line apart)
+        __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_build) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 22)) {  // ~ a second
+                g.counters[PAR_CNT_ERROR] = 1;
+                break;
+            }
+        }
+        if (__hip_atomic_fetch_add(left, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_build - 1) {
+            __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(left, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    // acquire: drop what this XCD's L2 holds of the handed-over lines (two XCDs write neighbouring nodes of one
+    // line; each keeps the line with its own part current and the other's stale). An invalidate, no write-back.
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+template <int ENT>
+__global__ __launch_bounds__(256) void build_fill_kernel(par_grid_dev g, par_bin_args b, par_render_args a,
+                                                          uint32_t out_rgba, int n_build, int2 part) {
+    stamp(g, a.flags, 0, 0);
+    if ((int)blockIdx.x < n_build) {
+        bin_insert_body<ENT, true>(g, b, (int)blockIdx.x, n_build);
+        build_barrier(g, n_build);
+        stamp(g, a.flags, 0, 3);
+        bin_resolve_body<true>(g, b, (int)blockIdx.x, n_build);
+    } else if (part.y != 0) {
+        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_build, (int)gridDim.x - n_build, part);
+    }
+    stamp(g, a.flags, 0, 7);
 }
 
 // Any plane, any geometry: one pixel per thread (parity / debugging planes and odd view sizes).
@@ -929,7 +1013,7 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
                 const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.nb.y, n);
                 if ((int)(int16_t)(d0 & 0xFFFF) == sz) {
                     woff = (int)(d1 & 0xFFFF);
-                    wcnt = (int)(d1 >> 16);
+                    wcnt = (int)(int16_t)(d1 >> 16);  // -1: the walk was too long to record
                 }
             }
         }
@@ -1170,7 +1254,7 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_
         render_items(g, a, w, n_item_wgs * PAR_WAVE_NW);
         return;
     }
-    const int j = b - n_item_wgs;
+    const int j = b - n_item_wgs;  // (workgroups of this kind exist only when some column may overflow)
     const int stride = ((int)gridDim.x - n_item_wgs) / over_parts;
     const int n_slow = g.counters[PAR_CNT_SLOW];
     for (int s = j / over_parts; s < n_slow; s += stride) {
@@ -1239,6 +1323,29 @@ hipError_t par_launch_bin_insert(const par_grid_dev& g, const par_bin_args& a, c
     } else {
         hipLaunchKernelGGL(bin_insert_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, stream, g, a);
     }
+    return hipGetLastError();
+}
+
+// The whole hash build in one launch (see build_fill_kernel) when the scene is small enough for a handful of
+// workgroups; hipErrorNotSupported (nothing launched) otherwise. With `fill`: also the fill shares of both launches.
+hipError_t par_launch_build(const par_grid_dev& g, const par_bin_args& a, int64_t pair_bound, const par_render_args* fa,
+                            const par_fill_plan* fill, hipStream_t stream) {
+    if (a.n > 16384 || pair_bound > 65536) return hipErrorNotSupported;
+    int64_t work = (int64_t)a.n * 4;  // ENT = 16 entities per wavefront: threads = n / 16 * 64
+    if (work < pair_bound) work = pair_bound;
+    int64_t blocks = (work + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 64) blocks = 64;  // (insert, the wipe and resolve all stride)
+    par_render_args none{};
+    int64_t nf = 0;
+    int2 part = make_int2(0, 0);
+    if (fill) {  // the chunks [cut[0], cut[2]): one chunk per wavefront and iteration, 4 wavefronts per workgroup
+        nf = ((int64_t)fill->cut[2] - fill->cut[0] + 3) / 4;
+        if (nf > 2 * PAR_FILL_RIDE_WGS) nf = 2 * PAR_FILL_RIDE_WGS;
+        part = make_int2(fill->cut[0], fill->cut[2]);
+    }
+    hipLaunchKernelGGL(build_fill_kernel<16>, dim3((unsigned)(blocks + nf)), dim3(256), 0, stream, g, a,
+                       fill ? *fa : none, fill ? fill->out_rgba : 0u, (int)blocks, part);
     return hipGetLastError();
 }
 
@@ -1342,13 +1449,13 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
 // Small frames: work items and overflowed columns in one launch. hipErrorNotSupported (nothing launched) for large
 // frames, where the two kernels' different register needs matter.
 hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
-                                  int64_t item_bound, hipStream_t stream) {
+                                  int64_t item_bound, bool may_overflow, hipStream_t stream) {
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     const int64_t bound = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (bound >= 2048 || a.dense) return hipErrorNotSupported;
     if (bound <= 0) return hipSuccess;
     const int over_parts = 8;
-    const int64_t over_cols = bound < 32 ? bound : 32;
+    const int64_t over_cols = !may_overflow ? 0 : (bound < 32 ? bound : 32);
     const int64_t n_item_wgs = item_workgroups(item_bound);
     hipLaunchKernelGGL(render_both_kernel, dim3((unsigned)(n_item_wgs + over_cols * over_parts)),
                        dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs, over_parts);

@@ -5,7 +5,8 @@
 // with par_update_aabbs_async. The reference's host is C++, so this is the loop a maintainer would write; it also
 // shows the frame rate without an interpreter in the submit path.
 //
-//   par_pipeline [--size S] [--prims N] [--frames F] [--inflight K] [--moving] [--check] [--flags X] [--stamps F0]
+//   par_pipeline [--size S] [--prims N] [--frames F] [--inflight K] [--threads T] [--moving] [--check] [--flags X]
+//                [--stamps F0]
 //
 // --flags X: render flags for every frame (the timing-experiment bits of par_raytracer.h; the output is then wrong).
 // --stamps F0 (with PAR_DEBUG_STAMPS=1 in the environment): the K frames from F0 on note the GPU's 100 MHz clock at
@@ -22,7 +23,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "par_raytracer.h"
@@ -62,7 +65,7 @@ static double now_s() {
 int main(int argc, char** argv) {
     int size = 4096, prims = 1024, frames = 2000, inflight = 4;
     bool moving = false, check = false;
-    int stamps_from = -1;
+    int stamps_from = -1, threads = 1;
     unsigned all_flags = 0;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -74,6 +77,7 @@ int main(int argc, char** argv) {
         else if (a == "--moving") moving = true;
         else if (a == "--check") check = true;
         else if (a == "--stamps") next(stamps_from);
+        else if (a == "--threads") next(threads);
         else if (a == "--flags") { int v = 0; next(v); all_flags = (unsigned)v; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -156,7 +160,24 @@ int main(int argc, char** argv) {
     for (int f = 0; f < warm; f++) if (submit(f)) return 1;
     HIP_OK(hipDeviceSynchronize());
     const double t0 = now_s();
-    for (int f = 0; f < frames; f++) if (submit(f)) return 1;
+    if (threads <= 1 || moving) {
+        for (int f = 0; f < frames; f++) if (submit(f)) return 1;
+    } else {
+        // one submitting thread per group of frame slots (a slot is only ever touched by its own thread)
+        std::atomic<int> failed{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) {
+            pool.emplace_back([&, t] {
+                (void)hipSetDevice(0);
+                for (int f = 0; f < frames; f++) {
+                    if ((f % inflight) % threads != t) continue;
+                    if (submit(f)) { failed = 1; return; }
+                }
+            });
+        }
+        for (auto& th : pool) th.join();
+        if (failed) return 1;
+    }
     const double t_enq = now_s() - t0;  // the host's share: time until the last frame was enqueued
     HIP_OK(hipDeviceSynchronize());
     const double dt = now_s() - t0;

@@ -57,15 +57,15 @@ def test_update_aabbs_between_frames(par, oracle, sprite, T):
 
 def test_overflowing_columns_take_the_overflow_kernel(par, oracle, sprite, T):
     # hundreds of boxes stacked into a few columns: more slot records / occluders than a column record holds
-    w, h, l = 480, 320, 320
+    w, h, l = 480, 320, 640
     params = T.default_params(w, h, l)
     rng = np.random.default_rng(2)
     rows = [(int(rng.integers(200, 260)), int(rng.integers(0, 40)), int(z), 20, 20, 20)
             for z in rng.integers(0, 300, 500)]
     rows += [(i * 20, 0, j * 20, 20, 20, 20) for i in range(24) for j in range(16) if not 4 <= i < 8]
-    # seven boxes in each of the eight z-bins of ONE screen column (y + z constant keeps them on the same rows):
-    # 56 slot records where a column record holds 48
-    rows += [(100 + k, 260 - 40 * b, 40 * b + 10, 20, 20, 20) for b in range(8) for k in range(7)]
+    # seven boxes in each of the sixteen z-bins of ONE screen column (y + z constant keeps them on the same rows):
+    # 112 slot records where a column record holds 64
+    rows += [(100 + k, 290 - 40 * b, 40 * b + 10, 20, 20, 20) for b in range(16) for k in range(7)]
     aabbs = T.make_aabbs(rows)
     for lpos in [(300, 160, 80), (230, 60, 10)]:
         light = T.make_light(*lpos)
@@ -80,8 +80,9 @@ def test_overflowing_columns_take_the_overflow_kernel(par, oracle, sprite, T):
 
 def test_long_shadow_walks_overflow_the_stage(par, oracle, sprite, T):
     # a row of full bins between the primitives and the light: the walk from the far end collects more occluder
-    # records (11 bins x 7) than a start bin's list (64) or the in-kernel stage holds, so those columns overflow
-    # and their shadow rays end in trace_hash_for_light as written, per lane
+    # records (11 bins x 7) than a start bin's list (64) holds, so the pixels starting there trace their shadow
+    # rays with trace_hash_for_light as written, per lane (the column keeps its record); PAR_FORCE_GENERIC
+    # (test_overflow_kernel_on_every_column) takes the same scene through the in-kernel stage, which overflows too
     w, h, l = 480, 320, 320
     params = T.default_params(w, h, l)
     rows = [(40 * bx + 2 * k, 100, 100, 20, 20, 20) for bx in range(12) for k in range(7)]
@@ -93,7 +94,7 @@ def test_long_shadow_walks_overflow_the_stage(par, oracle, sprite, T):
         with par.Renderer(params) as r:
             r.set_scene(aabbs, sprite, light)
             assert_planes_equal(r.render(ALL), exp, ALL, f"long walk {lpos}")
-            assert r.stats().overflow_columns > 0, "the walks are meant to overflow"
+            assert_planes_equal(r.render(("fb", "palidx")), exp, ("fb", "palidx"), f"long walk {lpos} (riding fill)")
 
 
 def test_shadow_rays_from_unoccupied_bins(par, oracle, T):
@@ -625,3 +626,36 @@ def test_cpp_pipeline_host(par):
         assert p.returncode == 0 and "check: ok" in p.stdout, p.stdout + p.stderr
         line = json.loads(p.stdout.splitlines()[0])
         assert line["host"] == "C++" and line["frames_per_s"] > 0
+
+
+def test_one_launch_hash_build_equals_two_launches(par, oracle, sprite, T):
+    """Small scenes build the spatial hash in ONE launch (insert, a barrier among the build workgroups, resolve)
+    instead of two. A moving scene, 120 frames with the riding fill in the same launches: every frame equals the
+    same frame built with two launches (flag bit 23), and every 20th the oracle's."""
+    import torch
+    w, h, l = 1024, 768, 640
+    params = T.default_params(w, h, l)
+    n = 700
+    aabbs, light = par.scene_synthetic(n, w, h, l, 77)
+    rng = np.random.default_rng(11)
+    vel = rng.choice([-5, 0, 5], size=(n, 3)).astype(np.int16)
+    bufs = [{k: torch.zeros(w * h * (4 if k == "fb" else 1), dtype=torch.uint8, device="cuda")
+             for k in ("fb", "palidx")} for _ in range(2)]
+    ptrs = [{k: v.data_ptr() for k, v in b.items()} for b in bufs]
+    stream = torch.cuda.Stream()
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        for f in range(120):
+            aabbs["px"] += vel[:, 0]
+            aabbs["py"] += vel[:, 1]
+            aabbs["pz"] += vel[:, 2]
+            r.update_aabbs(aabbs, 0, stream=stream.cuda_stream)
+            r.render_device(ptrs[0], stream=stream.cuda_stream)                  # one launch
+            r.render_device(ptrs[1], stream=stream.cuda_stream, flags=1 << 23)   # two launches
+            stream.synchronize()
+            for k in ("fb", "palidx"):
+                assert torch.equal(bufs[0][k], bufs[1][k]), f"frame {f} plane {k}: one-launch build differs"
+            if f % 20 == 0:
+                exp = oracle.render(params, aabbs, sprite, light, planes=("fb", "palidx"), nthreads=8)
+                assert np.array_equal(bufs[0]["fb"].cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
+                assert np.array_equal(bufs[0]["palidx"].cpu().numpy(), exp["palidx"]), f"frame {f}"

@@ -1,8 +1,8 @@
 #!/bin/bash
 # GPU box: frames in flight with parts of the frame switched off (flag bits 24-28; the output is then wrong by design)
 P=pixel-art-raytracer_amd/lib/par_pipeline
-run() { echo -n "$1: "; $P --frames 3000 --inflight ${3:-4} --flags $2 | grep -o '"us_per_frame": [0-9.]*'; }
-for k in 4 1; do
+run() { echo -n "$1: "; $P --frames 3000 --inflight ${3:-4} --threads ${3:-4} --flags $2 | grep -o '"us_per_frame": [0-9.]*'; }
+for k in 4; do
 echo "--- inflight $k"
 run "all                      " 0 $k
 run "no fill (28)             " $((1<<28)) $k
