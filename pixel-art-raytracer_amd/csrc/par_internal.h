@@ -60,7 +60,9 @@ struct par_colrec {
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");
 static_assert((PAR_COL_NB & (PAR_COL_NB - 1)) == 0 && PAR_COL_NB <= 64, "one occupied bin per lane");
-constexpr int PAR_COL_WAVES = 2;         // wavefronts per columns_kernel workgroup (one shadow walk each at a time)
+constexpr int PAR_COL_WAVES = 4;         // wavefronts per columns_kernel workgroup, independent of each other
+constexpr int PAR_COL_ROLES = 2;         // wavefronts that share the shadow walks of one column
+static_assert(PAR_COL_WAVES % PAR_COL_ROLES == 0 && PAR_COL_WALK % PAR_COL_ROLES == 0, "column workgroup layout");
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world
 // position (x, 0, 0) (alt:281, 707-709), so its ray starts in bin (x / B, H / B, 0) whatever its row -- one walk per

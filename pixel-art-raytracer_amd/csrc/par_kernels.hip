@@ -3,7 +3,7 @@
 // One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is five launches:
 //   insert_fill_kernel      bin_insert_body   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and
 //   resolve_fill_kernel     bin_resolve_body  }   deterministic (+ which screen columns show any primitive)
-//   columns_fill_kernel     columns_body: per occupied column its compact slot list and the bin walks of
+//   columns_fill_kernel     columns_wave: per occupied column its compact slot list and the bin walks of
 //                           trace_hash_for_light (alt:399-500; they depend on the start bin only) -> one record,
 //                           and one work item per 64-pixel chunk of the column's visit
 //   render_items_kernel     trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect
@@ -245,27 +245,6 @@ __global__ __launch_bounds__(256) void bin_resolve_kernel(par_grid_dev g, par_bi
 // Small device helpers
 // ------------------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) { return wave_incl_scan_i(v, lane); }
-
-// Exclusive prefix sum over a workgroup of NW wavefronts; two barriers. `total` is uniform.
-template <int NW>
-__device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum, int& total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int incl = wave_incl_scan(v, lane);
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    int base = 0;
-    total = 0;
-#pragma unroll
-    for (int i = 0; i < NW; i++) {
-        const int s = wsum[i];
-        if (i < w) base += s;
-        total += s;
-    }
-    __syncthreads();
-    return base + incl - v;
-}
-
 // std::min / std::max on floats: (b<a)?b:a and (a<b)?b:a -- the first argument survives a NaN (SURVEY a-5).
 __device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b : a; }
@@ -310,7 +289,7 @@ __device__ __forceinline__ int div_bin(int n, uint32_t magic) {
 // OR over the probes, so neither probe order nor duplicates matter.
 // ------------------------------------------------------------------------------------------------------------
 __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, const par_frame_dyn& dyn,
-                         int sx, int sy, int sz, int16_t (*chain)[65], par_slot* stage) {
+                         int sx, int sy, int sz, int16_t (*chain)[65], par_slot* stage, uint32_t sflags = 0) {
     const int lane = threadIdx.x & 63;
     const int b0 = flat_index(g.gy, g.gz, sx, sy, sz);  // alt:430
     // alt:406-430
@@ -326,14 +305,19 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
     for (int it0 = 0; it0 < m; it0 += 64) {
         const int n_it = min(64, m - it0);
         if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
+            // Always 64 steps, unrolled (a loop with a data-dependent trip count costs a taken branch per step, 2 us
+            // per walk): entries past n_it are never read, and a round shorter than 64 is the walk's last, so the
+            // carry is not needed after it either.
             float v = carry;
             chain[lane][0] = (int16_t)(int)v;  // alt:468
-            for (int q = 1; q <= n_it; q++) {
+#pragma unroll
+            for (int q = 1; q <= 64; q++) {
                 v = v + step_mine;
                 chain[lane][q] = (int16_t)(int)v;
             }
             carry = v;
         }
+        stamp(g, sflags, 2, 5);
         // written and read by the same wavefront: LDS operations of one wavefront complete in order; keep the
         // compiler from moving the reads above the writes
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -373,6 +357,7 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
         __builtin_amdgcn_wave_barrier();
         const int incl = wave_incl_scan_i(mine, lane);
         const int wave_total = __shfl(incl, 63);
+        stamp(g, sflags, 2, 6);
         if (n_rec + wave_total > PAR_BIN_WALK) return -1;
         int o = n_rec + incl - mine;
 #pragma unroll
@@ -388,103 +373,109 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// columns_body (columns_kernel, columns_fill_kernel): one workgroup (PAR_COL_WAVES wavefronts) per occupied screen
-// column (bx, by).
+// columns_wave (columns_kernel, columns_fill_kernel): one WAVEFRONT per occupied screen column (bx, by); a workgroup
+// is PAR_COL_WAVES independent wavefronts (no workgroup barrier anywhere: a column with one occupied bin does not
+// keep a second wavefront waiting for it).
 //   A. the column's bins, front to back: compact list of the occupied ones and their slot records;
-//   B. one wavefront per occupied bin walks from it to the light as trace_hash_for_light does (alt:399-500). The
-//      probed bin sequence depends only on the start and light bins, not on the ray, so it is done ONCE per bin
-//      and frame: the slot records of every occupied bin on the way (start bin excluded, alt:471-473) are kept.
-//      A pixel whose shadow ray starts in that bin only slab-tests the short list; the reference's result is an
-//      OR over probes, so neither probe order nor duplicates matter;
-//   C. how the pixels are to be visited (entry rectangles or the whole tile), which entries repeat an earlier
-//      entity, how many 64-pixel chunks that makes; the record goes to HBM/L2 for the render kernel.
+//   -  how the pixels are to be visited (entry rectangles or the whole tile), which entries repeat an earlier
+//      entity; the column's work items (one per 64-pixel chunk of the visit) are reserved in the render list;
+//   B. from every occupied bin the walk to the light as trace_hash_for_light does it (alt:399-500). The probed bin
+//      sequence depends only on the start and light bins, not on the ray, so it is done ONCE per bin and frame: the
+//      slot records of every occupied bin on the way (start bin excluded, alt:471-473) are kept. A pixel whose
+//      shadow ray starts in that bin only slab-tests the short list; the reference's result is an OR over probes,
+//      so neither probe order nor duplicates matter;
+//   C. the work items and the record go to HBM/L2 for the render kernel.
 // A column that does not fit the record (PAR_COL_*) goes onto the overflow list (render_overflow_kernel).
 // ------------------------------------------------------------------------------------------------------------
 
-struct ColShared {
+struct ColWave {  // LDS of one wavefront
     par_colrec_nb nb[PAR_COL_NB];
     par_slot entries[PAR_COL_ENT];
     int16_t ebz[PAR_COL_ENT];
-    par_slot stage[PAR_COL_WAVES][PAR_BIN_WALK];  // per wavefront: the records of the walk it is doing
-    int16_t chain[PAR_COL_WAVES][3][65];
-    int32_t wsum[PAR_COL_WAVES];
-    int32_t n_walk;
-    int32_t overflow;
-    int32_t chunks;
-    int32_t tile_mode;
-    uint32_t dup[2];
+    par_slot stage[PAR_BIN_WALK];  // the records of the walk being done
+    int16_t chain[3][65];
+    int16_t pad_;
 };
 
-__device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_render_args& a, ColShared& sm,
-                                             int block, int n_blocks) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // the last gx workgroups (when background rays are traced) walk from the background start bins instead
-    const int n_col_blocks = n_blocks - (a.trace_bg ? g.gx : 0);
-    if (block >= n_col_blocks) {
-        if (wave == 0) {
-            const int bx = block - n_col_blocks;
-            const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
-            // world (x, 0, 0): ray_bin = (x / B, (H - 0 - 0) / B, 0), alt:724-727
-            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, a.H / a.B, 0, sm.chain[0], sm.stage[0]);
-            par_bgwalk* out = g.bgwalk + bx;
-            for (int r = lane; r < n_rec; r += 64) out->rec[r] = sm.stage[0][r];
-            if (lane == 0) out->cnt = n_rec;
-        }
+// LDS written and read by the same wavefront: its LDS operations complete in order; keep the compiler from moving
+// reads above writes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// `ci`: index into the column list, or (when background rays are traced) n_cols_bound + bx for the walk from the
+// background start bin of bin column bx. `role`: PAR_COL_ROLES wavefronts share a column's walks (role r takes the
+// occupied bins r, r + roles, ... and the r-th part of the record's walk area); role 0 does everything else. The
+// others repeat the scan of the column's counts (they need the list of occupied bins) and leave at once when the
+// column has no walk for them.
+__device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_render_args& a, ColWave& sm, int ci,
+                                             int role, int n_cols_bound) {
+    const int lane = (int)threadIdx.x & 63;
+    if (ci >= n_cols_bound) {
+        const int bx = ci - n_cols_bound;
+        if (!a.trace_bg || bx >= g.gx || role != 0) return;
+        const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+        // world (x, 0, 0): ray_bin = (x / B, (H - 0 - 0) / B, 0), alt:724-727
+        const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, a.H / a.B, 0, sm.chain, sm.stage);
+        par_bgwalk* out = g.bgwalk + bx;
+        for (int r = lane; r < n_rec; r += 64) out->rec[r] = sm.stage[r];
+        if (lane == 0) out->cnt = n_rec;
         return;
     }
-    const int ci = block;
-    stamp(g, a.flags, 2, 0);
+    if (role == 0) stamp(g, a.flags, 2, 0);
     // the launch is sized by an upper bound of the occupied columns; both loads are issued together
     const int n_cols = g.counters[PAR_CNT_COLS];
     const int col = g.col_list[ci];
     if (ci >= n_cols) return;
-    stamp(g, a.flags, 2, 1);
+    if (role == 0) stamp(g, a.flags, 2, 1);
     const int bx = col / g.gy, by = col - (col / g.gy) * g.gy;
     const int col_base = flat_index(g.gy, g.gz, bx, by, 0);
-    if (tid == 0) {
-        sm.n_walk = 0;
-        sm.overflow = (ci >= g.col_capacity) ? 1 : 0;
-    }
+    bool overflow = ci >= g.col_capacity;
 
-    // ---- A: ordered compaction of the column ------------------------------------------------------------------
-    int nb_base = 0, ent_base = 0;
-    bool over = false;
-    for (int t0 = 0; t0 < g.gz; t0 += PAR_COL_WAVES * 64) {
-        const int t = t0 + tid;
-        const par_slot* src = a.slots + (size_t)(col_base + min(t, g.gz - 1)) * PAR_SLOTS;
-        const int c = (t < g.gz) ? (int)a.count[col_base + t] : 0;
-        int total;
-        const int packed = block_excl_scan<PAR_COL_WAVES>(((c != 0) << 16) | c, sm.wsum, total);
-        const int nb_i = nb_base + (packed >> 16);
-        const int off = ent_base + (packed & 0xFFFF);
+    // ---- A: ordered compaction of the column, 64 bins at a time (the next 64 counts are fetched meanwhile) -------
+    int n_nb = 0, n_entries = 0;
+    int c_next = (lane < g.gz) ? (int)a.count[col_base + lane] : 0;
+    for (int t0 = 0; t0 < g.gz; t0 += 64) {
+        const int t = t0 + lane;
+        const int c = c_next;
+        c_next = (t + 64 < g.gz) ? (int)a.count[col_base + t + 64] : 0;
+        const int incl = wave_incl_scan_i(((c != 0) << 16) | c, lane);
+        const int total = __shfl(incl, 63);
+        const int excl = incl - (((c != 0) << 16) | c);
+        const int nb_i = n_nb + (excl >> 16);
+        const int off = n_entries + (excl & 0xFFFF);
+        bool over = false;
         if (c != 0) {
             if (nb_i < PAR_COL_NB && off + c <= PAR_COL_ENT) {
+                const par_slot* src = a.slots + (size_t)(col_base + t) * PAR_SLOTS;
                 par_colrec_nb e;
                 e.bz = (int16_t)t; e.off = (uint8_t)off; e.cnt = (uint8_t)c; e.woff = 0; e.wcnt = 0;
                 sm.nb[nb_i] = e;
-                for (int k = 0; k < c; k++) {
-                    sm.entries[off + k] = src[k];
-                    sm.ebz[off + k] = (int16_t)t;
+                if (role == 0) {
+                    for (int k = 0; k < c; k++) {
+                        sm.entries[off + k] = src[k];
+                        sm.ebz[off + k] = (int16_t)t;
+                    }
                 }
             } else {
                 over = true;
             }
         }
-        nb_base += total >> 16;
-        ent_base += total & 0xFFFF;
+        overflow = overflow || __any(over);
+        n_nb += total >> 16;
+        n_entries += total & 0xFFFF;
     }
-    if (__syncthreads_or(over ? 1 : 0)) {
-        if (tid == 0) sm.overflow = 1;
-    }
-    __syncthreads();
-    const int n_nb = nb_base, n_entries = ent_base;
-    stamp(g, a.flags, 2, 2);
+    wave_lds_fence();
+    if (role == 0) stamp(g, a.flags, 2, 2);
+    if (role != 0 && (overflow || n_nb <= role)) return;  // no walk for this wavefront
 
     // ---- how the render kernel should visit the column's pixels: entry rectangle by entry rectangle when they
     // cover little of it (the lanes of a 64-pixel chunk are then nearly all covered pixels), otherwise the whole
     // tile. An entry that repeats an earlier entry's entity (the same AABB in another bin of the column) has the
     // same rectangle and owns no pixel: it is marked and skipped. Every 64-pixel chunk of the visit becomes one
-    // work item of the render launch. All of it is wavefront 0's (at most PAR_COL_ENT <= 64 entries: one per lane).
+    // work item of the render launch (at most PAR_COL_ENT <= 64 entries: one per lane).
     // The column's share of its shard of the item list is reserved here, BEFORE the walks, with one atomic on one of
     // PAR_ITEM_SHARDS words that lie a cache line apart: its result is needed only after the walks, which hide its
     // latency.
@@ -492,73 +483,63 @@ __device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_re
     const int rows_lo = max(by * a.B, a.row_begin), rows_hi = min(min((by + 1) * a.B, a.H), a.row_end);
     const int tile_chunks = (tw * max(rows_hi - rows_lo, 0) + 63) >> 6;
     const int shard = ci & (PAR_ITEM_SHARDS - 1);
-    int my_chunks = 0, first_item = 0, n_items = 0, item_base = 0, tile_mode = 0;
-    if (wave == 0) {
-        bool dup = false;
-        if (!sm.overflow && lane < n_entries) {
-            const par_slot r = sm.entries[lane];
-            for (int e = 0; e < lane; e++) dup = dup || (sm.entries[e].entity == r.entity);
-            const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
-            const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
-            if (!dup && w > 0 && h > 0) my_chunks = (w * h + 63) >> 6;  // every visit costs whole wavefronts
-        }
-        const uint64_t dup_mask = __ballot(dup);
-        const int incl = wave_incl_scan_i(my_chunks, lane);
-        const int pass_chunks = __shfl(incl, 63);
-        first_item = incl - my_chunks;
-        tile_mode = (pass_chunks >= tile_chunks) ? 1 : 0;
-        n_items = sm.overflow ? 0 : (tile_mode ? tile_chunks : pass_chunks);
-        if (lane == 0) {
-            if (n_items > 0) item_base = atomicAdd(&g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], n_items);
-            sm.chunks = n_items;
-            sm.dup[0] = (uint32_t)dup_mask;
-            sm.dup[1] = (uint32_t)(dup_mask >> 32);
-            sm.tile_mode = tile_mode;
-        }
+    int my_chunks = 0;
+    bool dup = false;
+    if (role == 0 && !overflow && lane < n_entries) {
+        const par_slot r = sm.entries[lane];
+        for (int e = 0; e < lane; e++) dup = dup || (sm.entries[e].entity == r.entity);
+        const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
+        const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
+        if (!dup && w > 0 && h > 0) my_chunks = (w * h + 63) >> 6;  // every visit costs whole wavefronts
     }
+    const uint64_t dup_mask = __ballot(dup);
+    const int chunk_incl = wave_incl_scan_i(my_chunks, lane);
+    const int pass_chunks = __shfl(chunk_incl, 63);
+    const int first_item = chunk_incl - my_chunks;
+    const int tile_mode = (pass_chunks >= tile_chunks) ? 1 : 0;
+    const int n_items = (overflow || role != 0) ? 0 : (tile_mode ? tile_chunks : pass_chunks);
+    int item_base = 0;
+    if (lane == 0 && n_items > 0) item_base = atomicAdd(&g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], n_items);
 
-    // ---- B: the shadow walks, one wavefront per occupied bin --------------------------------------------------
-    if (!sm.overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
+    // ---- B: the shadow walks of this wavefront's share of the occupied bins, one after the other ---------------
+    constexpr int kWalkPart = PAR_COL_WALK / PAR_COL_ROLES;
+    const int walk_lo = role * kWalkPart;
+    int n_walk = 0;
+    if (!overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
         const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
-        int16_t(*chain)[65] = sm.chain[wave];
-        par_slot* stage = sm.stage[wave];
-        for (int i = wave; i < n_nb; i += PAR_COL_WAVES) {  // wave-uniform
+        for (int i = role; i < n_nb; i += PAR_COL_ROLES) {
             const int sz = sm.nb[i].bz;
-            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, chain, stage);
-            const bool w_over = n_rec < 0;
-            // reserve this bin's part of the column's walk area and copy the staged records out
-            int woff = 0;
-            if (lane == 0 && !w_over) woff = atomicAdd(&sm.n_walk, n_rec);
-            woff = __shfl(woff, 0);
-            if (w_over || woff + n_rec > PAR_COL_WALK) {
+            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, sm.chain, sm.stage, i == 0 ? a.flags : 0u);
+            if (n_rec < 0 || n_walk + n_rec > kWalkPart) {
                 // more occluders on the way than the record holds: the pixels that start here walk for themselves
                 // (lane_shadow_walk in the render kernel), the column keeps its record
                 if (lane == 0) {
-                    if (!w_over) atomicSub(&sm.n_walk, n_rec);
                     sm.nb[i].woff = 0;
                     sm.nb[i].wcnt = -1;
                 }
             } else {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                par_slot* dst = g.colrec[ci].walk + woff;
-                for (int r = lane; r < n_rec; r += 64) dst[r] = stage[r];
+                par_slot* dst = g.colrec[ci].walk + walk_lo + n_walk;
+                for (int r = lane; r < n_rec; r += 64) dst[r] = sm.stage[r];
                 if (lane == 0) {
-                    sm.nb[i].woff = (int16_t)woff;
+                    sm.nb[i].woff = (int16_t)(walk_lo + n_walk);
                     sm.nb[i].wcnt = (int16_t)n_rec;
                 }
+                n_walk += n_rec;
             }
+            wave_lds_fence();  // (the next walk overwrites the stage)
         }
     }
-    __syncthreads();
-    stamp(g, a.flags, 2, 3);
+    if (role == 0) stamp(g, a.flags, 2, 3);
+    if (role != 0) {  // the other wavefronts' part of the record: the bins they walked from
+        if (ci < g.col_capacity && lane < n_nb && lane % PAR_COL_ROLES == role) g.colrec[ci].nb[lane] = sm.nb[lane];
+        return;
+    }
 
-    // ---- the column's work items (none of them usable when a walk overflowed the record meanwhile, or when the
-    // shard is full: the host sizes a shard for every item of the frame, so that is belt and braces) --------------
-    if (wave == 0 && n_items > 0) {
+    // ---- C: the column's work items (none of them usable when the shard is full: the host sizes a shard for every
+    // item of the frame, so that is belt and braces) and the record -------------------------------------------
+    if (n_items > 0) {
         item_base = __shfl(item_base, 0);
-        const bool usable = !sm.overflow && item_base + n_items <= g.item_capacity;
+        const bool usable = item_base + n_items <= g.item_capacity;
         uint2* dst = g.items + (size_t)shard * g.item_capacity + item_base;
         const uint32_t id = usable ? (uint32_t)ci : PAR_ITEM_NONE;
         if (tile_mode) {
@@ -572,41 +553,47 @@ __device__ __forceinline__ void columns_body(const par_grid_dev& g, const par_re
                 }
             }
         }
-        if (!usable && lane == 0) sm.overflow = 1;
+        overflow = overflow || !usable;
     }
-    __syncthreads();
-    const bool overflow_final = sm.overflow != 0;
-
-    // ---- C: the record ----------------------------------------------------------------------------------------
     if (ci < g.col_capacity) {
         par_colrec* rec = g.colrec + ci;
-        if (tid == 0) {
-            rec->n_nb = (int16_t)(overflow_final ? 0 : n_nb);
-            rec->n_entries = (int16_t)(overflow_final ? 0 : n_entries);
-            rec->n_walk = (int16_t)sm.n_walk;
-            rec->overflow = overflow_final ? 1 : 0;
+        if (lane == 0) {
+            rec->n_nb = (int16_t)(overflow ? 0 : n_nb);
+            rec->n_entries = (int16_t)(overflow ? 0 : n_entries);
+            rec->n_walk = (int16_t)n_walk;  // (of this wavefront's share)
+            rec->overflow = overflow ? 1 : 0;
             rec->bx = (int16_t)bx;
             rec->by = (int16_t)by;
-            rec->tile_mode = sm.tile_mode;
-            rec->chunks = sm.chunks;
-            rec->dup_lo = sm.dup[0];
-            rec->dup_hi = sm.dup[1];
+            rec->tile_mode = tile_mode;
+            rec->chunks = n_items;
+            rec->dup_lo = (uint32_t)dup_mask;
+            rec->dup_hi = (uint32_t)(dup_mask >> 32);
         }
-        if (!overflow_final) {
-            if (tid < n_nb) rec->nb[tid] = sm.nb[tid];
-            if (tid < n_entries) {
-                rec->entries[tid] = sm.entries[tid];
-                rec->ebz[tid] = sm.ebz[tid];
+        if (!overflow) {
+            if (lane < n_nb && lane % PAR_COL_ROLES == 0) rec->nb[lane] = sm.nb[lane];
+            if (lane < n_entries) {
+                rec->entries[lane] = sm.entries[lane];
+                rec->ebz[lane] = sm.ebz[lane];
             }
         }
     }
-    if (overflow_final && tid == 0) g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;  // the exception
+    if (overflow && lane == 0) g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;  // the exception
     stamp(g, a.flags, 2, 4);
 }
 
-__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a) {
-    __shared__ ColShared sm;
-    columns_body(g, a, sm, (int)blockIdx.x, (int)gridDim.x);
+// `n_col_blocks` workgroups of PAR_COL_WAVES columns each; `n_cols_bound` bounds the column list (the wavefronts past
+// it do the background walks when background rays are traced).
+__device__ __forceinline__ void columns_block(const par_grid_dev& g, const par_render_args& a, ColWave* sm, int block,
+                                              int n_cols_bound) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    columns_wave(g, a, sm[wave], block * (PAR_COL_WAVES / PAR_COL_ROLES) + wave / PAR_COL_ROLES, wave % PAR_COL_ROLES,
+                 n_cols_bound);
+}
+
+__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a,
+                                                                      int n_cols_bound) {
+    __shared__ ColWave sm[PAR_COL_WAVES];
+    columns_block(g, a, sm, (int)blockIdx.x, n_cols_bound);
     stamp(g, a.flags, 2, 7);
 }
 
@@ -709,13 +696,14 @@ __global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t o
 // 16 Mpixel frame: one launch for both (the first `n_col` workgroups build column records, the others fill), so the
 // fill costs the frame's launch chain neither a link nor its own duration.
 __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_fill_kernel(par_grid_dev g, par_render_args a,
-                                                                          uint32_t out_rgba, int n_col, int2 part) {
-    __shared__ ColShared sm;
-    if ((int)blockIdx.x < n_col) {
-        columns_body(g, a, sm, (int)blockIdx.x, n_col);
+                                                                          uint32_t out_rgba, int n_col_blocks,
+                                                                          int n_cols_bound, int2 part) {
+    __shared__ ColWave sm[PAR_COL_WAVES];
+    if ((int)blockIdx.x < n_col_blocks) {
+        columns_block(g, a, sm, (int)blockIdx.x, n_cols_bound);
     } else {
         stamp(g, a.flags, 2, 0);
-        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col, (int)gridDim.x - n_col, part);
+        fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col_blocks, (int)gridDim.x - n_col_blocks, part);
     }
     stamp(g, a.flags, 2, 7);
 }
@@ -1363,14 +1351,24 @@ hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, 
     return hipGetLastError();
 }
 
+// Columns of the launch: the occupied columns (at most `column_bound`, at most those of the rendered rows) and, when
+// background rays are traced, one background walk per bin column; PAR_COL_WAVES of them per workgroup.
+static int64_t column_blocks(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, int64_t* n_cols) {
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    int64_t n = column_bound < cols_in_range ? column_bound : cols_in_range;
+    if (n < 0) n = 0;
+    *n_cols = n;
+    if (a.trace_bg) n += g.gx;  // the background walks
+    constexpr int kPerBlock = PAR_COL_WAVES / PAR_COL_ROLES;
+    return (n + kPerBlock - 1) / kPerBlock;
+}
+
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                               hipStream_t stream) {
-    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
-    int64_t blocks = column_bound < cols_in_range ? column_bound : cols_in_range;
-    if (blocks < 0) blocks = 0;
-    if (a.trace_bg) blocks += g.gx;  // the background walks
+    int64_t n_cols;
+    const int64_t blocks = column_blocks(g, a, column_bound, &n_cols);
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(PAR_COL_WAVES * 64), 0, stream, g, a);
+    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(PAR_COL_WAVES * 64), 0, stream, g, a, (int)n_cols);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !a.trace_bg) return e;
     hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
@@ -1380,14 +1378,12 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
 // Column records + the last share of the fill in one launch.
 hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                    const par_fill_plan& fill, hipStream_t stream) {
-    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
-    int64_t n_col = column_bound < cols_in_range ? column_bound : cols_in_range;
-    if (n_col < 0) n_col = 0;
-    if (a.trace_bg) n_col += g.gx;  // the background walks
+    int64_t n_cols;
+    const int64_t n_col_blocks = column_blocks(g, a, column_bound, &n_cols);
     int64_t n_fill = fill_blocks(fill, 2, PAR_COL_WAVES, 4 * PAR_FILL_RIDE_WGS);
-    if (n_col + n_fill <= 0) return hipSuccess;
-    hipLaunchKernelGGL(columns_fill_kernel, dim3((unsigned)(n_col + n_fill)), dim3(PAR_COL_WAVES * 64), 0, stream, g,
-                       a, fill.out_rgba, (int)n_col, make_int2(fill.cut[2], fill.cut[3]));
+    if (n_col_blocks + n_fill <= 0) return hipSuccess;
+    hipLaunchKernelGGL(columns_fill_kernel, dim3((unsigned)(n_col_blocks + n_fill)), dim3(PAR_COL_WAVES * 64), 0, stream,
+                       g, a, fill.out_rgba, (int)n_col_blocks, (int)n_cols, make_int2(fill.cut[2], fill.cut[3]));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !a.trace_bg) return e;
     hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);

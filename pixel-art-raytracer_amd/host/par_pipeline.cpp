@@ -205,7 +205,7 @@ int main(int argc, char** argv) {
         for (size_t k = 0; k < slots.size(); k++) {
             const int f = stamps_from + (int)((k + slots.size() - (size_t)stamps_from % slots.size()) % slots.size());
             for (size_t r = 0; r < rows; r++) {
-                unsigned long long a0 = ~0ull, a1 = 0, last_start = 0;
+                unsigned long long a0 = ~0ull, a1 = 0, last_start = 0, life = 0;
                 size_t cnt = 0;
                 for (size_t i = 0; i < wgs; i++) {
                     const unsigned long long b = st[k][(r * wgs + i) * 8], e = st[k][(r * wgs + i) * 8 + 7];
@@ -214,11 +214,14 @@ int main(int argc, char** argv) {
                     a0 = std::min(a0, b);
                     last_start = std::max(last_start, b);
                     a1 = std::max(a1, std::max(b, e));
+                    if (e > b) life += e - b;
                 }
                 if (!cnt) continue;
-                std::printf("stamps frame %d slot %zu %-16s start %8.2f  last-wg-start %8.2f  end %8.2f  (%.2f us, %zu wgs)\n",
+                static const int waves[5] = {4, 4, 2, 2, 2};  // wavefronts per workgroup of each kernel
+                std::printf("stamps frame %d slot %zu %-16s start %8.2f  last-wg-start %8.2f  end %8.2f  (%.2f us, %zu wgs, "
+                            "%.0f wavefront-us)\n",
                             f, k, names[r], (a0 - t_min) * 0.01, (last_start - t_min) * 0.01, (a1 - t_min) * 0.01,
-                            (a1 - a0) * 0.01, cnt);
+                            (a1 - a0) * 0.01, cnt, life * 0.01 * waves[r]);
             }
         }
     }
