@@ -44,7 +44,8 @@ enum {
     PAR_RENDER_TRACE_BACKGROUND = 1u << 0,
     /* Count the shadow rays actually traced into par_frame_stats (one atomic per workgroup). */
     PAR_RENDER_COUNT_RAYS = 1u << 1
-    /* Bit 23 (tests): build the spatial hash with two launches even where one would do; same pixels.
+    /* Bit 22 (tests): no self-contained work items, every column is rendered from its record; same pixels.
+     * Bit 23 (tests): build the spatial hash with two launches even where one would do; same pixels.
      * Bits 24-28 switch parts of the frame OFF for timing experiments (tools/ablate.py, tools/overlap.py): the output
      * is then wrong by design. Never set them in a render whose pixels are used. Bit 29: debug time stamps. */
 };

@@ -188,7 +188,7 @@ int ensure_items(par_context* ctx, int64_t items, int64_t cols) {
     if (ctx->grid.items) PAR_HIP(hipFree(ctx->grid.items));
     ctx->grid.items = nullptr;
     ctx->grid.item_capacity = 0;
-    PAR_HIP(hipMalloc(&ctx->grid.items, (size_t)cap * PAR_ITEM_SHARDS * sizeof(uint2)));
+    PAR_HIP(hipMalloc(&ctx->grid.items, (size_t)cap * PAR_ITEM_SHARDS * sizeof(par_item)));
     ctx->grid.item_capacity = (int32_t)cap;
     return PAR_OK;
 }

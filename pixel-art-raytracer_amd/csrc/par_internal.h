@@ -60,8 +60,8 @@ struct par_colrec {
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");
 static_assert((PAR_COL_NB & (PAR_COL_NB - 1)) == 0 && PAR_COL_NB <= 64, "one occupied bin per lane");
-constexpr int PAR_COL_WAVES = 4;         // wavefronts per columns_kernel workgroup, independent of each other
 constexpr int PAR_COL_ROLES = 2;         // wavefronts that share the shadow walks of one column
+constexpr int PAR_COL_WAVES = PAR_COL_ROLES;  // wavefronts per columns_kernel workgroup: those of one column
 static_assert(PAR_COL_WAVES % PAR_COL_ROLES == 0 && PAR_COL_WALK % PAR_COL_ROLES == 0, "column workgroup layout");
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world
@@ -80,6 +80,27 @@ struct par_frame_dyn {
     int32_t lbx, lby, lbz;  // its bin (alt:729-732)
 };
 
+constexpr int PAR_WAVE_NW = 2;          // wavefronts per render workgroup
+// Render work items: columns_kernel lists every 64-pixel chunk of every column with a record as one item (par_item);
+// pass = the entry whose rectangle is visited, PAR_ITEM_TILE = the whole tile. An item of a SIMPLE column (all its
+// entries are one entity, every shadow walk from its bins met no occupied bin: most columns of a sparse scene)
+// carries all the render kernel needs, which then never touches the column's record. The list is kept in PAR_ITEM_SHARDS shards (column index mod shards), each with its own counter, so
+// that the column workgroups' appends do not queue up on one address; wavefront w of the render launch takes items
+// w / shards, + waves / shards, ... of shard w mod shards.
+constexpr int PAR_ITEM_SHARD_BITS = 6;
+constexpr int PAR_ITEM_SHARDS = 1 << PAR_ITEM_SHARD_BITS;
+constexpr int PAR_ITEM_COUNTER_STRIDE = 32;  // int32 words between two shard counters: one 128-byte line each
+constexpr uint32_t PAR_ITEM_TILE = 0xFFFFu;
+constexpr uint32_t PAR_ITEM_NONE = 0xFFFFFFFFu;  // a reserved item slot whose column went to the overflow list
+struct par_item {
+    uint32_t ci;        // index of the column (list and record), or PAR_ITEM_NONE
+    uint32_t visit;     // (pass << 16) | chunk of the pass
+    uint32_t where;     // bx | by << 10 | PAR_ITEM_SIMPLE
+    uint32_t bins;      // simple columns: first | last << 16 of the (contiguous) occupied bins
+    par_slot entry;     // the pass's entry (entry passes)
+};
+static_assert(sizeof(par_item) == 32, "work item layout");
+constexpr uint32_t PAR_ITEM_SIMPLE = 1u << 31;
 struct par_grid_dev {
     int32_t gx, gy, gz, volume;
     int32_t* head[2];         // [volume] node index + 1 of the most recent insertion, 0 = none
@@ -93,7 +114,7 @@ struct par_grid_dev {
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
     int32_t* counters;        // [PAR_CNT_TOTAL]: occupied columns, overflowed columns (reset by insert)
     par_colrec* colrec;       // [col_capacity] indexed like col_list
-    uint2* items;             // [PAR_ITEM_SHARDS * item_capacity] render work items: one 64-pixel chunk each
+    par_item* items;          // [PAR_ITEM_SHARDS * item_capacity] render work items: one 64-pixel chunk each
     int32_t* item_counters;   // [PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE] items per shard (reset by insert)
     int32_t* build_sync;      // [64] barrier words of build_fill_kernel (arrived, left; they reset themselves)
     int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
@@ -137,17 +158,6 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
-constexpr int PAR_WAVE_NW = 2;          // wavefronts per render workgroup
-// Render work items: columns_kernel lists every 64-pixel chunk of every column with a record as one item
-// {column index, (pass << 16) | chunk of the pass}; pass = the entry whose rectangle is visited, PAR_ITEM_TILE = the
-// whole tile. The list is kept in PAR_ITEM_SHARDS shards (column index mod shards), each with its own counter, so
-// that the column workgroups' appends do not queue up on one address; wavefront w of the render launch takes items
-// w / shards, + waves / shards, ... of shard w mod shards.
-constexpr int PAR_ITEM_SHARD_BITS = 6;
-constexpr int PAR_ITEM_SHARDS = 1 << PAR_ITEM_SHARD_BITS;
-constexpr int PAR_ITEM_COUNTER_STRIDE = 32;  // int32 words between two shard counters: one 128-byte line each
-constexpr uint32_t PAR_ITEM_TILE = 0xFFFFu;
-constexpr uint32_t PAR_ITEM_NONE = 0xFFFFFFFFu;  // a reserved item slot whose column went to the overflow list
 enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_ERROR = 2, PAR_CNT_TOTAL = 8 };
 
 // The background fill split over the frame's first three launches: 512-pixel chunks [cut[i], cut[i+1]) go with

@@ -55,6 +55,37 @@ __device__ __forceinline__ T ld_shared(const T* p) {
     return *p;
 }
 
+// Wave-uniform data that an EARLIER launch wrote (work items, their counters): read through the scalar cache. The
+// compiler only does that by itself for memory it can prove unchanged during the kernel; the constant address
+// space says so.
+template <typename T>
+__device__ __forceinline__ T ld_uniform(const T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const T __attribute__((address_space(4))) * cptr;
+    return *(cptr)(uintptr_t)p;
+#else
+    return *p;
+#endif
+}
+
+// A 32-byte work item, fetched with ONE scalar load that is issued here and waited for in item_arrived: the
+// compiler would sink an ordinary load below the branch on the item counter, a dependent round trip later.
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ u32x8 item_fetch(const par_item* p) {
+    u32x8 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(v) : "s"(p) : "memory");
+#else
+    v = *reinterpret_cast<const u32x8*>(p);
+#endif
+    return v;
+}
+__device__ __forceinline__ void item_arrived(u32x8& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v) : : "memory");
+#endif
+}
+
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -410,8 +441,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 // occupied bins r, r + roles, ... and the r-th part of the record's walk area); role 0 does everything else. The
 // others repeat the scan of the column's counts (they need the list of occupied bins) and leave at once when the
 // column has no walk for them.
-__device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_render_args& a, ColWave& sm, int ci,
-                                             int role, int n_cols_bound) {
+__device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_render_args& a, ColWave& sm,
+                                             int32_t* others_found, int ci, int role, int n_cols_bound) {
     const int lane = (int)threadIdx.x & 63;
     if (ci >= n_cols_bound) {
         const int bx = ci - n_cols_bound;
@@ -505,6 +536,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     constexpr int kWalkPart = PAR_COL_WALK / PAR_COL_ROLES;
     const int walk_lo = role * kWalkPart;
     int n_walk = 0;
+    bool walk_failed = false;
     if (!overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
         const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
         for (int i = role; i < n_nb; i += PAR_COL_ROLES) {
@@ -513,6 +545,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
             if (n_rec < 0 || n_walk + n_rec > kWalkPart) {
                 // more occluders on the way than the record holds: the pixels that start here walk for themselves
                 // (lane_shadow_walk in the render kernel), the column keeps its record
+                walk_failed = true;
                 if (lane == 0) {
                     sm.nb[i].woff = 0;
                     sm.nb[i].wcnt = -1;
@@ -530,6 +563,16 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
         }
     }
     if (role == 0) stamp(g, a.flags, 2, 3);
+    // Did any walk of the column meet an occupied bin (or fail to fit)? The wavefronts of a column are its whole
+    // workgroup, and all of them are still here exactly when the column has a walk for each (the same test in all
+    // of them): then, and only then, they meet at a barrier.
+    bool walks_empty = n_walk == 0 && !walk_failed;
+    if (!overflow && n_nb >= PAR_COL_ROLES) {
+        static_assert(PAR_COL_ROLES == 2, "one other wavefront writes the word");
+        if (role != 0 && lane == 0) *others_found = walks_empty ? 0 : 1;
+        __syncthreads();
+        if (role == 0) walks_empty = walks_empty && *others_found == 0;
+    }
     if (role != 0) {  // the other wavefronts' part of the record: the bins they walked from
         if (ci < g.col_capacity && lane < n_nb && lane % PAR_COL_ROLES == role) g.colrec[ci].nb[lane] = sm.nb[lane];
         return;
@@ -540,17 +583,28 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     if (n_items > 0) {
         item_base = __shfl(item_base, 0);
         const bool usable = item_base + n_items <= g.item_capacity;
-        uint2* dst = g.items + (size_t)shard * g.item_capacity + item_base;
-        const uint32_t id = usable ? (uint32_t)ci : PAR_ITEM_NONE;
+        // A SIMPLE column: every entry is the same entity (one distinct entry), its occupied bins are contiguous and
+        // no walk from them met anything. Its items carry all the render kernel needs.
+        const int distinct = n_entries - __popcll(dup_mask);
+        const int bz_first = sm.nb[0].bz, bz_last = sm.nb[max(n_nb, 1) - 1].bz;
+        const bool simple = !(a.flags & (1u << 22)) && distinct == 1 && walks_empty && !tile_mode && n_nb >= 1 &&
+                            bz_last - bz_first == n_nb - 1;  // bit 22 (tests): no simple items
+        par_item it;
+        it.ci = usable ? (uint32_t)ci : PAR_ITEM_NONE;
+        it.where = (uint32_t)bx | ((uint32_t)by << 10) | (simple ? PAR_ITEM_SIMPLE : 0u);
+        it.bins = (uint32_t)bz_first | ((uint32_t)bz_last << 16);
+        par_item* dst = g.items + (size_t)shard * g.item_capacity + item_base;
         if (tile_mode) {
+            it.entry = par_slot{0, 0, 0, 0, 0, 0, 0};
             for (int k = lane; k < n_items; k += 64) {
-                if (item_base + k < g.item_capacity) dst[k] = make_uint2(id, (PAR_ITEM_TILE << 16) | (uint32_t)k);
+                it.visit = (PAR_ITEM_TILE << 16) | (uint32_t)k;
+                if (item_base + k < g.item_capacity) dst[k] = it;
             }
         } else {
+            if (my_chunks > 0) it.entry = sm.entries[lane];
             for (int k = 0; k < my_chunks; k++) {
-                if (item_base + first_item + k < g.item_capacity) {
-                    dst[first_item + k] = make_uint2(id, ((uint32_t)lane << 16) | (uint32_t)k);
-                }
+                it.visit = ((uint32_t)lane << 16) | (uint32_t)k;
+                if (item_base + first_item + k < g.item_capacity) dst[first_item + k] = it;
             }
         }
         overflow = overflow || !usable;
@@ -583,17 +637,18 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
 
 // `n_col_blocks` workgroups of PAR_COL_WAVES columns each; `n_cols_bound` bounds the column list (the wavefronts past
 // it do the background walks when background rays are traced).
-__device__ __forceinline__ void columns_block(const par_grid_dev& g, const par_render_args& a, ColWave* sm, int block,
-                                              int n_cols_bound) {
+__device__ __forceinline__ void columns_block(const par_grid_dev& g, const par_render_args& a, ColWave* sm,
+                                              int32_t* others_found, int block, int n_cols_bound) {
+    static_assert(PAR_COL_WAVES == PAR_COL_ROLES, "a column's wavefronts are its whole workgroup (columns_wave's barrier)");
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    columns_wave(g, a, sm[wave], block * (PAR_COL_WAVES / PAR_COL_ROLES) + wave / PAR_COL_ROLES, wave % PAR_COL_ROLES,
-                 n_cols_bound);
+    columns_wave(g, a, sm[wave], others_found, block, wave, n_cols_bound);
 }
 
 __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a,
                                                                       int n_cols_bound) {
     __shared__ ColWave sm[PAR_COL_WAVES];
-    columns_block(g, a, sm, (int)blockIdx.x, n_cols_bound);
+    __shared__ int32_t others_found;
+    columns_block(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
     stamp(g, a.flags, 2, 7);
 }
 
@@ -699,8 +754,9 @@ __global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_fill_kernel(par_gr
                                                                           uint32_t out_rgba, int n_col_blocks,
                                                                           int n_cols_bound, int2 part) {
     __shared__ ColWave sm[PAR_COL_WAVES];
+    __shared__ int32_t others_found;
     if ((int)blockIdx.x < n_col_blocks) {
-        columns_block(g, a, sm, (int)blockIdx.x, n_cols_bound);
+        columns_block(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
     } else {
         stamp(g, a.flags, 2, 0);
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col_blocks, (int)gridDim.x - n_col_blocks, part);
@@ -886,6 +942,18 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
     const int32_t* depth0 = a.sprites[0].depth;
+    // An entry pass visits the rectangle of entry `own`: its texel is the likeliest winner of the lane's pixel, so
+    // what the shading needs of it (normal, colour, palette index) is fetched now, beside the primary pass's depth
+    // lookups, instead of a dependent round trip after them. (With a sprite-id table the texel is not known yet.)
+    int pre_tex = -1, pre_pal = 0;
+    par_texel pre_ti = par_texel{0.f, 0.f, 0.f, 0u};
+    if (!GENERIC && own >= 0 && valid && !a.sprite_ids) {
+        const par_slot r = slot_of_lane(cr.ent, own);
+        const int sprite_row = r.py + r.ey + r.pz + r.ez - (int)(int16_t)(H - row);  // alt:324-326
+        pre_tex = sprite_row * PAR_SPRITE_W + (col - r.px);                           // alt:330-332
+        pre_ti = a.texinfo[pre_tex];
+        if (a.out.palidx) pre_pal = a.sprites[0].color[pre_tex];
+    }
     // ---- primary ray, alt:271-397: the column's slot records front to back ------------------------------------
     bool hit = false;
     int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;
@@ -974,13 +1042,17 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
     int sy = 0, sz = 0, ox = 0, oy = 0, oz = 0;
     if (shade) {
         // normal (alt:349-350) + resolved palette colour (alt:352-354)
-        const par_texel ti = a.texinfo[p_tex];
+        par_texel ti = pre_ti;
+        pal_index = pre_pal;
+        if (p_tex != pre_tex) {  // another entry won (or nothing was fetched ahead)
+            ti = a.texinfo[p_tex];
+            if (a.out.palidx) {
+                const int sid = p_tex / PAR_SPRITE_TEXELS;
+                pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
+            }
+        }
         nx = ti.nx; ny = ti.ny; nz = ti.nz;
         rgba = ti.rgba;
-        if (a.out.palidx) {
-            const int sid = p_tex / PAR_SPRITE_TEXELS;
-            pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
-        }
         const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
         // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
         const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
@@ -1135,17 +1207,40 @@ __device__ __forceinline__ void render_column_generic(const par_grid_dev& g, con
 // they arrive through the scalar cache; the entry and bin tables sit one element per lane in registers
 // (v_readlane). No LDS, no barrier, no loop over chunks: every wavefront of the launch is a handful of dependent
 // loads long, whatever its column looks like.
-__device__ __forceinline__ void render_item(const par_grid_dev& g, const par_render_args& a, int ci, uint32_t pass,
-                                            int chunk, int lane) {
+// The item as two 16-byte words (par_item: {ci, visit, where, bins}, {entry}).
+__device__ __forceinline__ void render_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, uint4 ib,
+                                            int lane) {
+    const int ci = (int)ia.x;
+    const uint32_t pass = ia.y >> 16;
+    const int chunk = (int)(ia.y & 0xFFFFu);
+    const bool simple = (ia.z & PAR_ITEM_SIMPLE) != 0;
     const par_colrec& rec_ = g.colrec[ci];
     ColumnRegs cr;
-    cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
-    cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
-    cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
-    const int n_entries_rec = rec_.n_entries, n_nb = rec_.n_nb;
-    const int bx = rec_.bx, by = rec_.by;
-    const uint64_t dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
-    if (rec_.overflow) return;  // render_overflow_kernel's
+    int n_entries_rec, n_nb, bx, by;
+    uint64_t dup;
+    if (simple) {
+        // all the column has to say is in the item: one entry (every lane holds it; it is entry 0 of the list and
+        // the pass), the occupied bins bins.first .. bins.last, each with an empty walk
+        const int bz_first = (int)(ia.w & 0xFFFFu), bz_last = (int)(ia.w >> 16);
+        cr.ent = ib;  // (par_slot as it lies in memory)
+        cr.ebz = bz_first;
+        cr.nb = make_uint2((uint32_t)(uint16_t)(bz_first + lane), 0u);  // lane n: bin first + n, walk [0, 0)
+        n_entries_rec = 1;
+        n_nb = bz_last - bz_first + 1;
+        bx = (int)(ia.z & 0x3FFu);
+        by = (int)((ia.z >> 10) & 0x3FFu);
+        dup = 0;
+    } else {
+        cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
+        cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
+        cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
+        n_entries_rec = rec_.n_entries;
+        n_nb = rec_.n_nb;
+        bx = rec_.bx;
+        by = rec_.by;
+        dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
+        if (rec_.overflow) return;  // render_overflow_kernel's
+    }
     const int n_entries = (a.flags & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
     const int W = a.W, H = a.H, B = a.B;
     const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
@@ -1153,7 +1248,8 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const int tw = min(B, W - c0);
     const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
     const bool tile_mode = pass == PAR_ITEM_TILE;
-    const int own = tile_mode ? -1 : (int)pass;
+    // (a simple column's only entry sits in every lane: it is read as entry 0 whatever its index in the record was)
+    const int own = tile_mode ? -1 : (simple ? 0 : (int)pass);
     int rx0, rw, ry0, rh;
     if (tile_mode) {
         rx0 = c0; rw = tw; ry0 = rows_lo; rh = rows_hi - rows_lo;
@@ -1190,15 +1286,21 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
 __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
     const int lane = (int)threadIdx.x & 63;
     const int shard = w & (PAR_ITEM_SHARDS - 1);
-    const uint2* list = g.items + (size_t)shard * g.item_capacity;
+    const par_item* list = g.items + (size_t)shard * g.item_capacity;
     const int first = w >> PAR_ITEM_SHARD_BITS;
     // the first item is fetched beside the counter (the list is allocated whatever the counter says)
-    uint2 it = list[min(first, g.item_capacity - 1)];
-    const int n = min(g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], g.item_capacity);
+    u32x8 it = item_fetch(list + min(first, g.item_capacity - 1));
+    const int n = min(ld_uniform(g.item_counters + shard * PAR_ITEM_COUNTER_STRIDE), g.item_capacity);
+    item_arrived(it);
     for (int i = first; i < n;) {
-        if (it.x != PAR_ITEM_NONE) render_item(g, a, (int)it.x, it.y >> 16, (int)(it.y & 0xFFFFu), lane);
+        if (it[0] != PAR_ITEM_NONE) {
+            render_item(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
+        }
         i += n_waves >> PAR_ITEM_SHARD_BITS;
-        if (i < n) it = list[i];
+        if (i < n) {
+            it = item_fetch(list + i);
+            item_arrived(it);
+        }
     }
 }
 

@@ -630,8 +630,10 @@ def test_cpp_pipeline_host(par):
 
 def test_one_launch_hash_build_equals_two_launches(par, oracle, sprite, T):
     """Small scenes build the spatial hash in ONE launch (insert, a barrier among the build workgroups, resolve)
-    instead of two. A moving scene, 120 frames with the riding fill in the same launches: every frame equals the
-    same frame built with two launches (flag bit 23), and every 20th the oracle's."""
+    instead of two, and the work items of columns that hold one entity and cast no shadow on themselves carry all the
+    render kernel needs (it never reads their record). A moving scene, 120 frames with the riding fill in the same
+    launches: every frame equals the same frame built with two launches (flag bit 23) and rendered through the
+    records only (flag bit 22), and every 20th the oracle's."""
     import torch
     w, h, l = 1024, 768, 640
     params = T.default_params(w, h, l)
@@ -640,7 +642,7 @@ def test_one_launch_hash_build_equals_two_launches(par, oracle, sprite, T):
     rng = np.random.default_rng(11)
     vel = rng.choice([-5, 0, 5], size=(n, 3)).astype(np.int16)
     bufs = [{k: torch.zeros(w * h * (4 if k == "fb" else 1), dtype=torch.uint8, device="cuda")
-             for k in ("fb", "palidx")} for _ in range(2)]
+             for k in ("fb", "palidx")} for _ in range(3)]
     ptrs = [{k: v.data_ptr() for k, v in b.items()} for b in bufs]
     stream = torch.cuda.Stream()
     with par.Renderer(params) as r:
@@ -652,9 +654,11 @@ def test_one_launch_hash_build_equals_two_launches(par, oracle, sprite, T):
             r.update_aabbs(aabbs, 0, stream=stream.cuda_stream)
             r.render_device(ptrs[0], stream=stream.cuda_stream)                  # one launch
             r.render_device(ptrs[1], stream=stream.cuda_stream, flags=1 << 23)   # two launches
+            r.render_device(ptrs[2], stream=stream.cuda_stream, flags=1 << 22)   # every work item through its record
             stream.synchronize()
             for k in ("fb", "palidx"):
                 assert torch.equal(bufs[0][k], bufs[1][k]), f"frame {f} plane {k}: one-launch build differs"
+                assert torch.equal(bufs[0][k], bufs[2][k]), f"frame {f} plane {k}: self-contained work items differ"
             if f % 20 == 0:
                 exp = oracle.render(params, aabbs, sprite, light, planes=("fb", "palidx"), nthreads=8)
                 assert np.array_equal(bufs[0]["fb"].cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"

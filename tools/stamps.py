@@ -43,13 +43,13 @@ for row, name in enumerate(["insert+fill", "resolve+fill", "columns+fill", "rend
         fill = idx >= idx.max() - 255
         print(f"    fill workgroups (last 256): life median {np.median(d[fill]):5.2f} max {d[fill].max():5.2f}; end of the "
               f"last one {e[fill].max()-t0:6.2f}; end of the last column workgroup {e[~fill].max()-t0:6.2f} us")
-x2 = st[2][:(ncol + 1) // 2]
+x2 = st[2][:ncol]
 ok = (x2[:, 5] > 0) & (x2[:, 6] > 0)
 print(f"first walk of a column ({ok.sum()} columns): A done -> chain computed median {np.median(x2[ok,5]-x2[ok,2]):.2f} p90 {np.percentile(x2[ok,5]-x2[ok,2],90):.2f}; "
       f"chain -> counts loaded median {np.median(x2[ok,6]-x2[ok,5]):.2f} p90 {np.percentile(x2[ok,6]-x2[ok,5],90):.2f}; "
       f"counts -> walks done median {np.median(x2[ok,3]-x2[ok,6]):.2f} p90 {np.percentile(x2[ok,3]-x2[ok,6],90):.2f} us")
 for k, name, labels in ((2, "columns_body", ["start", "listed", "A done", "B walks done", "end"]),):
-    x = st[k][:(ncol + 1) // 2]
+    x = st[k][:ncol]
     live = x[:, 4] > 0
     x = x[live]
     t0 = x[:, 0].min()
