@@ -80,7 +80,7 @@ struct par_frame_dyn {
     int32_t lbx, lby, lbz;  // its bin (alt:729-732)
 };
 
-constexpr int PAR_WAVE_NW = 2;          // wavefronts per render workgroup
+constexpr int PAR_WAVE_NW = 4;          // wavefronts per render workgroup
 // Render work items: columns_kernel lists every 64-pixel chunk of every column with a record as one item (par_item);
 // pass = the entry whose rectangle is visited, PAR_ITEM_TILE = the whole tile. An item of a SIMPLE column (all its
 // entries are one entity, every shadow walk from its bins met no occupied bin: most columns of a sparse scene)

@@ -1030,6 +1030,7 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         }
     }
 
+    if (!GENERIC) stamp(g, a.flags, 3, 3);
     // ---- shading, alt:704-758 ---------------------------------------------------------------------------------
     float nx = 0.f, ny = 0.f, nz = 0.f;
     uint32_t rgba = bg_rgba;
@@ -1131,6 +1132,7 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
     }
     if (shade) bright = lit ? b_lit : ambient;
     const bool lit_px = lit;
+    if (!GENERIC) stamp(g, a.flags, 3, 4);
     if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
         const unsigned long long m = __ballot(valid && hit);
         if (lane == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
@@ -1241,6 +1243,14 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
         dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
         if (rec_.overflow) return;  // render_overflow_kernel's
     }
+    stamp(g, a.flags, 3, 2);
+    // The shadow test will read the walk list of the pixel's start bin, which is known only after the primary pass
+    // and its depth lookups: lane n touches the first line of bin n's list now, so that those reads find it in the
+    // cache instead of adding a round trip to memory at the end of the chain.
+    uint32_t touched = 0;
+    if (!simple && lane < n_nb && (int)(int16_t)(cr.nb.y >> 16) > 0) {
+        touched = *reinterpret_cast<const uint32_t*>(rec_.walk + (cr.nb.y & 0xFFFFu));
+    }
     const int n_entries = (a.flags & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
     const int W = a.W, H = a.H, B = a.B;
     const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
@@ -1279,6 +1289,7 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
     render_chunk<false>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, pidx < area,
                         lane, nullptr);
+    asm volatile("" ::"v"(touched));  // (keeps the touch alive; nothing reads it)
 }
 
 // Wavefront `w` of `n_waves` (a multiple of PAR_ITEM_SHARDS): items w / shards, + n_waves / shards, ... of shard
@@ -1292,6 +1303,7 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     u32x8 it = item_fetch(list + min(first, g.item_capacity - 1));
     const int n = min(ld_uniform(g.item_counters + shard * PAR_ITEM_COUNTER_STRIDE), g.item_capacity);
     item_arrived(it);
+    stamp(g, a.flags, 3, 1);
     for (int i = first; i < n;) {
         if (it[0] != PAR_ITEM_NONE) {
             render_item(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);

@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
     bool moving = false, check = false;
     int stamps_from = -1, threads = 1;
     unsigned all_flags = 0;
+    std::string scene = "synthetic";
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto next = [&](int& v) { if (i + 1 < argc) v = std::atoi(argv[++i]); };
@@ -78,17 +79,35 @@ int main(int argc, char** argv) {
         else if (a == "--check") check = true;
         else if (a == "--stamps") next(stamps_from);
         else if (a == "--threads") next(threads);
+        else if (a == "--scene") { if (i + 1 < argc) scene = argv[++i]; }
         else if (a == "--flags") { int v = 0; next(v); all_flags = (unsigned)v; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (inflight < 1 || inflight > 16 || frames < 1) return 2;
-    const int W = size, H = size, L = size;
+    // --scene synthetic (default; --size, --prims) | floor (a full floor of tiles at --size: every pixel covered) |
+    //         graybox (the reference's own 480x320 world, alt:517-599)
+    int W = size, H = size, L = size;
     par_params params;
     par_default_params(&params);
-    params.width = W; params.height = H; params.length = L;
-    std::vector<par_aabb> aabbs((size_t)prims);
+    std::vector<par_aabb> aabbs;
     par_light light;
-    par_scene_synthetic(prims, W, H, L, 12345, aabbs.data(), &light);
+    if (scene == "graybox") {
+        W = 480; H = 320; L = 320;
+        aabbs.resize((size_t)par_scene_graybox(W, L, nullptr, 0));
+        par_scene_graybox(W, L, aabbs.data(), (int)aabbs.size());
+        light.x = 480; light.y = 160; light.z = 80; light.radius = 10;  // alt:625-626
+    } else if (scene == "floor") {
+        for (int i = 0; i < W / 20; i++) {
+            for (int j = 0; j < L / 20; j++) aabbs.push_back(par_aabb{(int16_t)(i * 20), 0, (int16_t)(j * 20), 20, 20, 20, {0, 0}});
+        }
+        light.x = (int16_t)(5 * W / 8); light.y = (int16_t)(H / 2); light.z = (int16_t)(L / 4); light.radius = 10;
+    } else {
+        aabbs.resize((size_t)prims);
+        par_scene_synthetic(prims, W, H, L, 12345, aabbs.data(), &light);
+    }
+    prims = (int)aabbs.size();
+    size = W;
+    params.width = W; params.height = H; params.length = L;
     par_sprite sprite;
     par_sprite_tile_floor(&sprite);
     // +-5 or 0 per axis and frame, from a fixed little generator

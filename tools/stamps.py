@@ -43,6 +43,15 @@ for row, name in enumerate(["insert+fill", "resolve+fill", "columns+fill", "rend
         fill = idx >= idx.max() - 255
         print(f"    fill workgroups (last 256): life median {np.median(d[fill]):5.2f} max {d[fill].max():5.2f}; end of the "
               f"last one {e[fill].max()-t0:6.2f}; end of the last column workgroup {e[~fill].max()-t0:6.2f} us")
+x3 = st[3]
+ok3 = (x3[:, 0] > 0) & (x3[:, 1] > 0) & (x3[:, 2] > 0) & (x3[:, 3] > 0) & (x3[:, 4] > 0) & (x3[:, 7] > 0)
+if ok3.any():
+    names3 = ["start", "item arrived", "record read", "primary pass done", "shadow test done", "end (stores issued)"]
+    idx3 = [0, 1, 2, 3, 4, 7]
+    print(f"render wavefront 0 of {ok3.sum()} workgroups that rendered an item:")
+    for i in range(1, 6):
+        d = x3[ok3, idx3[i]] - x3[ok3, idx3[i - 1]]
+        print(f"   {names3[i-1]:>20s} -> {names3[i]:<20s}: median {np.median(d):5.2f}  p90 {np.percentile(d,90):5.2f}  max {d.max():5.2f} us")
 x2 = st[2][:ncol]
 ok = (x2[:, 5] > 0) & (x2[:, 6] > 0)
 print(f"first walk of a column ({ok.sum()} columns): A done -> chain computed median {np.median(x2[ok,5]-x2[ok,2]):.2f} p90 {np.percentile(x2[ok,5]-x2[ok,2],90):.2f}; "
