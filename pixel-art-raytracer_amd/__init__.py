@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "par_update_aabbs_async",
     "par_set_light", "par_render", "par_render_rows", "par_render_device", "par_render_device_timed",
     "par_graph_capture", "par_graph_stage", "par_graph_launch", "par_pick", "par_get_stats", "par_read_grid",
-    "par_sprite_tile_floor", "par_scene_graybox", "par_scene_synthetic", "par_debug_line",
+    "par_sprite_tile_floor", "par_scene_graybox", "par_scene_synthetic", "par_debug_line", "par_debug_units",
 )
 
 
@@ -108,10 +108,26 @@ def lib():
         L.par_sprite_tile_floor.argtypes = [vp]
         L.par_scene_graybox.argtypes = [i32, i32, vp, i32]
         L.par_scene_synthetic.argtypes = [i32, i32, i32, i32, C.c_uint64, vp, vp]
+        L.par_debug_units.argtypes = [i32, i32, vp, vp, i32, vp]
         L.par_debug_line.restype = None
         L.par_debug_line.argtypes = [vp, vp, i32, vp, vp]
         _lib = L
     return _lib
+
+
+def debug_units(kind, in_a, in_b=None, device=0):
+    """The reference's arithmetic units as the device kernels compute them (par_debug_units). kind 0: intersect
+    (AABB[n], RAY[n]) -> uint8[n]; 1: color scale (float32[n, 5]) -> uint8[n, 4]; 2: normalize (float32[n, 3]) ->
+    float32[n, 3]."""
+    a = np.ascontiguousarray(in_a)
+    b = None if in_b is None else np.ascontiguousarray(in_b)
+    n = len(a)
+    out = np.zeros(n, dtype=np.uint8) if kind == 0 else (np.zeros((n, 4), dtype=np.uint8) if kind == 1
+                                                         else np.zeros((n, 3), dtype=np.float32))
+    rc = lib().par_debug_units(device, kind, ptr(a), ptr(b), n, ptr(out))
+    if rc != PAR_OK:
+        raise ParError(rc, "par_debug_units")
+    return out
 
 
 def device_count():
@@ -238,13 +254,14 @@ class Renderer:
         """Asynchronous render into device memory. `device_ptrs` maps plane name -> raw device pointer (int) that
         addresses (row_begin, 0). `stream` is a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream)."""
         r0, r1 = rows or (0, self.height)
-        # (the Outputs struct of a pointer set is cached: this is the per-frame call of a render loop)
-        key = id(device_ptrs)
-        cached = self._out_cache.get(key)
-        if cached is None or cached[0] is not device_ptrs:
-            cached = (device_ptrs, Outputs(*[device_ptrs.get(k) for k in _PLANES]))
-            self._out_cache[key] = cached
-        o = cached[1]
+        # (the Outputs struct of a pointer set is cached by the pointer VALUES: this is the per-frame call of a render
+        # loop, and a caller may well put a new pointer into the same dict)
+        key = tuple(device_ptrs.get(k) for k in _PLANES)
+        o = self._out_cache.get(key)
+        if o is None:
+            if len(self._out_cache) >= 64:
+                self._out_cache.clear()
+            o = self._out_cache[key] = Outputs(*key)
         if timed:
             st = FrameStats()
             self._check(lib().par_render_device_timed(self._ctx, C.c_void_p(stream), r0, r1, C.byref(o), flags,

@@ -4,6 +4,7 @@
 // it owns the work arrays (alt:503-517), takes the scene the caller built (alt:517-599, 619-626), and runs one
 // frame = bin + trace + shade (alt:690-760) per render call. There is no CPU rendering path in this library.
 #include <algorithm>
+#include <new>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -54,8 +55,14 @@ struct par_context {
     // hipGraph path: one executable graph per grid set, a pinned staging area they copy from
     hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
     hipGraph_t graph[2] = {nullptr, nullptr};
-    par_aabb* pin_aabbs = nullptr;
-    par_frame_dyn* pin_dyn = nullptr;
+    // Each graph copies the scene from a pinned staging area of its own (the copy node reads it when the graph RUNS,
+    // which may be long after it was launched): the area of set s is rewritten only after the event recorded behind
+    // set s's last launch. `stage_lo/hi`: entities changed since the area last matched the host mirror.
+    par_aabb* pin_aabbs[2] = {nullptr, nullptr};
+    par_frame_dyn* pin_dyn[2] = {nullptr, nullptr};
+    hipEvent_t ev_graph[2] = {nullptr, nullptr};
+    bool ev_graph_pending[2] = {false, false};
+    int stage_lo[2] = {0, 0}, stage_hi[2] = {0, 0};
     par_aabb* pin_update = nullptr;   // staging of par_update_aabbs_async
     int pin_update_capacity = 0;
     hipEvent_t ev_update = nullptr;   // its last copy
@@ -77,8 +84,31 @@ namespace {
 constexpr size_t kPlaneElem[5] = {sizeof(par_color), sizeof(par_pixel), 1, sizeof(float), 1};
 
 int fail(par_context* c, int status, const std::string& msg) {
-    if (c) c->err = msg;
+    if (c) {
+        try {
+            c->err = msg;
+        } catch (...) {  // (the message is a convenience; the status is the contract)
+        }
+    }
     return status;
+}
+
+// No exception crosses the C boundary (par_raytracer.h): every entry point that allocates on the host runs its
+// body through this. PAR_TEST_BAD_ALLOC=1 (tests) makes the guarded bodies fail as an exhausted heap would.
+void test_alloc_hook() {
+    const char* e = std::getenv("PAR_TEST_BAD_ALLOC");
+    if (e && e[0] == '1') throw std::bad_alloc();
+}
+
+template <class F>
+int guarded(par_context* ctx, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, PAR_ERR_OOM, "host allocation failed");
+    } catch (...) {
+        return fail(ctx, PAR_ERR_HIP, "unexpected C++ exception");
+    }
 }
 
 int hip_fail(par_context* c, hipError_t e, const char* what) {
@@ -234,6 +264,20 @@ void drop_graphs(par_context* c) {
         if (c->graph[s]) (void)hipGraphDestroy(c->graph[s]);
         c->graph_exec[s] = nullptr;
         c->graph[s] = nullptr;
+    }
+}
+
+// Entities [first, first + n) changed on the host: both graphs' staging areas are stale there.
+void mark_staged(par_context* c, int first, int n) {
+    if (n <= 0) return;
+    for (int s = 0; s < 2; s++) {
+        if (c->stage_hi[s] <= c->stage_lo[s]) {
+            c->stage_lo[s] = first;
+            c->stage_hi[s] = first + n;
+        } else {
+            c->stage_lo[s] = std::min(c->stage_lo[s], first);
+            c->stage_hi[s] = std::max(c->stage_hi[s], first + n);
+        }
     }
 }
 
@@ -446,7 +490,7 @@ int par_device_count(void) {
     return n;
 }
 
-int par_create(const par_params* params, int device, par_context** out) {
+static int par_create_impl(const par_params* params, int device, par_context** out) {
     if (!params || !out) return PAR_ERR_INVALID_ARG;
     *out = nullptr;
     const par_params& p = *params;
@@ -558,8 +602,11 @@ void par_destroy(par_context* ctx) {
     }
     if (ctx->pin_update) (void)hipHostFree(ctx->pin_update);
     if (ctx->ev_update) (void)hipEventDestroy(ctx->ev_update);
-    if (ctx->pin_aabbs) (void)hipHostFree(ctx->pin_aabbs);
-    if (ctx->pin_dyn) (void)hipHostFree(ctx->pin_dyn);
+    for (int s = 0; s < 2; s++) {
+        if (ctx->pin_aabbs[s]) (void)hipHostFree(ctx->pin_aabbs[s]);
+        if (ctx->pin_dyn[s]) (void)hipHostFree(ctx->pin_dyn[s]);
+        if (ctx->ev_graph[s]) (void)hipEventDestroy(ctx->ev_graph[s]);
+    }
     for (int i = 0; i < 5; i++) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     }
@@ -567,8 +614,9 @@ void par_destroy(par_context* ctx) {
     delete ctx;
 }
 
-int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) {
+static int par_set_sprites_impl(par_context* ctx, const par_sprite* sprites, int n_sprites) {
     if (!ctx || !sprites || n_sprites <= 0) return fail(ctx, PAR_ERR_INVALID_ARG, "sprites");
+    test_alloc_hook();
     for (int s = 0; s < n_sprites; s++) {
         for (int t = 0; t < PAR_SPRITE_TEXELS; t++) {
             const int c = sprites[s].color[t];
@@ -579,6 +627,7 @@ int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) 
     }
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
+    drop_graphs(ctx);  // (a captured graph bakes the table's pointers)
     if (ctx->d_sprites) PAR_HIP(hipFree(ctx->d_sprites));
     ctx->d_sprites = nullptr;
     ctx->n_sprites = 0;
@@ -602,8 +651,9 @@ int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) 
     return PAR_OK;
 }
 
-int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* sprite_ids, int n) {
+static int par_set_entities_impl(par_context* ctx, const par_aabb* aabbs, const int32_t* sprite_ids, int n) {
     if (!ctx || n < 0 || (n > 0 && !aabbs)) return fail(ctx, PAR_ERR_INVALID_ARG, "entities");
+    test_alloc_hook();
     int max_id = 0;
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) {
@@ -661,20 +711,36 @@ int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* spr
     return PAR_OK;
 }
 
-int par_set_entities_ref_layout(par_context* ctx, const par_aabb* aabbs, const par_sprite* sprite_per_entity, int n) {
+static int par_set_entities_ref_layout_impl(par_context* ctx, const par_aabb* aabbs, const par_sprite* sprite_per_entity, int n) {
     if (!ctx || n < 0 || (n > 0 && (!aabbs || !sprite_per_entity))) return fail(ctx, PAR_ERR_INVALID_ARG, "entities");
-    // The reference stores one 16 000-byte Sprite per entity (alt:95,107). Keep each distinct sprite once.
-    std::unordered_map<std::string, int32_t> seen;
+    // The reference stores one 16 000-byte Sprite per entity (alt:95,107). Keep each distinct sprite once: a 64-bit
+    // hash of the bytes finds the candidates, memcmp decides.
+    test_alloc_hook();
+    std::unordered_map<uint64_t, std::vector<int32_t>> seen;
     std::vector<par_sprite> table;
     std::vector<int32_t> ids((size_t)n);
     for (int i = 0; i < n; i++) {
-        std::string key(reinterpret_cast<const char*>(&sprite_per_entity[i]), sizeof(par_sprite));
-        auto it = seen.find(key);
-        if (it == seen.end()) {
-            it = seen.emplace(std::move(key), (int32_t)table.size()).first;
-            table.push_back(sprite_per_entity[i]);
+        const unsigned char* bytes = reinterpret_cast<const unsigned char*>(&sprite_per_entity[i]);
+        uint64_t h = 1469598103934665603ull;  // FNV-1a over 8-byte words
+        for (size_t k = 0; k + 8 <= sizeof(par_sprite); k += 8) {
+            uint64_t w;
+            std::memcpy(&w, bytes + k, 8);
+            h = (h ^ w) * 1099511628211ull;
         }
-        ids[(size_t)i] = it->second;
+        std::vector<int32_t>& bucket = seen[h];
+        int32_t id = -1;
+        for (int32_t cand : bucket) {
+            if (std::memcmp(&table[(size_t)cand], bytes, sizeof(par_sprite)) == 0) {
+                id = cand;
+                break;
+            }
+        }
+        if (id < 0) {
+            id = (int32_t)table.size();
+            table.push_back(sprite_per_entity[i]);
+            bucket.push_back(id);
+        }
+        ids[(size_t)i] = id;
     }
     if (table.empty()) {
         par_sprite s;
@@ -686,7 +752,7 @@ int par_set_entities_ref_layout(par_context* ctx, const par_aabb* aabbs, const p
     return par_set_entities(ctx, aabbs, ids.data(), n);
 }
 
-int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) {
+static int par_update_aabbs_impl(par_context* ctx, const par_aabb* aabbs, int first, int n) {
     if (!ctx || !aabbs || first < 0 || n < 0 || !ctx->have_entities || first + n > ctx->n_entities) {
         return fail(ctx, PAR_ERR_INVALID_ARG, "update range outside the uploaded entities");
     }
@@ -722,15 +788,15 @@ int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) 
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
         ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
-        if (ctx->pin_aabbs) ctx->pin_aabbs[first + i] = aabbs[i];  // a captured graph uploads from here
     }
     ctx->total_pairs = total;
     ctx->total_cols = total_cols;
     ctx->total_items = total_items;
+    mark_staged(ctx, first, n);  // (a captured graph uploads the scene from its staging area)
     return PAR_OK;
 }
 
-int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, int n, void* stream_v) {
+static int par_update_aabbs_async_impl(par_context* ctx, const par_aabb* aabbs, int first, int n, void* stream_v) {
     if (!ctx || !aabbs || first < 0 || n < 0 || !ctx->have_entities || first + n > ctx->n_entities) {
         return fail(ctx, PAR_ERR_INVALID_ARG, "update range outside the uploaded entities");
     }
@@ -779,37 +845,38 @@ int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, i
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
         ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
         ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
-        if (ctx->pin_aabbs) ctx->pin_aabbs[first + i] = aabbs[i];  // a captured graph uploads from here
     }
     ctx->total_pairs = total;
     ctx->total_cols = total_cols;
     ctx->total_items = total_items;
+    mark_staged(ctx, first, n);  // (a captured graph uploads the scene from its staging area)
     return PAR_OK;
 }
 
-int par_set_light(par_context* ctx, const par_light* light) {
+static int par_set_light_impl(par_context* ctx, const par_light* light) {
     if (!ctx || !light) return fail(ctx, PAR_ERR_INVALID_ARG, "light");
     ctx->light = *light;
     ctx->have_light = true;
     return PAR_OK;
 }
 
-int par_render(par_context* ctx, const par_outputs* host_out, unsigned flags) {
+static int par_render_impl(par_context* ctx, const par_outputs* host_out, unsigned flags) {
     if (!ctx) return PAR_ERR_INVALID_ARG;
     return render_to_host(ctx, 0, ctx->params.height, host_out, flags);
 }
 
-int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outputs* host_out, unsigned flags) {
+static int par_render_rows_impl(par_context* ctx, int row_begin, int row_end, const par_outputs* host_out, unsigned flags) {
     return render_to_host(ctx, row_begin, row_end, host_out, flags);
 }
 
-int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
+static int par_render_device_impl(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
                       unsigned flags) {
     if (!ctx || !device_out) return fail(ctx, PAR_ERR_INVALID_ARG, "null argument");
     int rc = check_rows(ctx, row_begin, row_end);
     if (rc != PAR_OK) return rc;
     rc = check_ready(ctx);
     if (rc != PAR_OK) return rc;
+    PAR_HIP(hipSetDevice(ctx->device));
     rc = enqueue_frame(ctx, (hipStream_t)stream, ctx->set, row_begin, row_end, *device_out, flags, false, nullptr);
     if (rc != PAR_OK) return rc;
     ctx->set ^= 1;
@@ -819,13 +886,14 @@ int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end
     return PAR_OK;
 }
 
-int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int row_end,
+static int par_render_device_timed_impl(par_context* ctx, void* stream, int row_begin, int row_end,
                             const par_outputs* device_out, unsigned flags, par_frame_stats* stats) {
     if (!ctx || !device_out) return fail(ctx, PAR_ERR_INVALID_ARG, "null argument");
     int rc = check_rows(ctx, row_begin, row_end);
     if (rc != PAR_OK) return rc;
     rc = check_ready(ctx);
     if (rc != PAR_OK) return rc;
+    PAR_HIP(hipSetDevice(ctx->device));
     rc = enqueue_frame(ctx, (hipStream_t)stream, ctx->set, row_begin, row_end, *device_out, flags, false, ctx->ev);
     if (rc != PAR_OK) return rc;
     ctx->set ^= 1;
@@ -839,7 +907,7 @@ int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int r
     return PAR_OK;
 }
 
-int par_graph_capture(par_context* ctx, void* stream_v, int row_begin, int row_end, const par_outputs* device_out,
+static int par_graph_capture_impl(par_context* ctx, void* stream_v, int row_begin, int row_end, const par_outputs* device_out,
                       unsigned flags) {
     if (!ctx || !device_out) return fail(ctx, PAR_ERR_INVALID_ARG, "null argument");
     hipStream_t stream = (hipStream_t)stream_v;
@@ -863,34 +931,47 @@ int par_graph_capture(par_context* ctx, void* stream_v, int row_begin, int row_e
     }
     rc = ensure_items(ctx, ctx->graph_item_bound, ctx->graph_pair_bound);
     if (rc != PAR_OK) return rc;
-    if (!ctx->pin_aabbs) {
-        PAR_HIP(hipHostMalloc(&ctx->pin_aabbs, (size_t)std::max(ctx->aabb_capacity, 1) * sizeof(par_aabb), hipHostMallocDefault));
-        PAR_HIP(hipHostMalloc(&ctx->pin_dyn, sizeof(par_frame_dyn), hipHostMallocDefault));
+    for (int s = 0; s < 2; s++) {
+        if (!ctx->pin_aabbs[s]) {
+            PAR_HIP(hipHostMalloc(&ctx->pin_aabbs[s], (size_t)std::max(ctx->aabb_capacity, 1) * sizeof(par_aabb), hipHostMallocDefault));
+        }
+        if (!ctx->pin_dyn[s]) PAR_HIP(hipHostMalloc(&ctx->pin_dyn[s], sizeof(par_frame_dyn), hipHostMallocDefault));
+        if (!ctx->ev_graph[s]) PAR_HIP(hipEventCreateWithFlags(&ctx->ev_graph[s], hipEventDisableTiming));
+        ctx->ev_graph_pending[s] = false;
+        std::memcpy(ctx->pin_aabbs[s], ctx->h_aabbs.data(), (size_t)ctx->n_entities * sizeof(par_aabb));
+        *ctx->pin_dyn[s] = make_dyn(ctx, ctx->light);
+        ctx->stage_lo[s] = ctx->stage_hi[s] = 0;
     }
-    std::memcpy(ctx->pin_aabbs, ctx->h_aabbs.data(), (size_t)ctx->n_entities * sizeof(par_aabb));
-    *ctx->pin_dyn = make_dyn(ctx, ctx->light);
     // The frame alternates between the two grid sets, and a captured kernel node bakes its pointers: one graph
-    // per set, launched alternately.
+    // per set, launched alternately; each uploads the scene from its own staging area.
     for (int s = 0; s < 2; s++) {
         PAR_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        hipError_t e = hipMemcpyAsync(ctx->d_aabbs, ctx->pin_aabbs, (size_t)ctx->n_entities * sizeof(par_aabb),
+        hipError_t e = hipMemcpyAsync(ctx->d_aabbs, ctx->pin_aabbs[s], (size_t)ctx->n_entities * sizeof(par_aabb),
                                       hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_dyn, ctx->pin_dyn, sizeof(par_frame_dyn), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_dyn, ctx->pin_dyn[s], sizeof(par_frame_dyn), hipMemcpyHostToDevice, stream);
         int erc = PAR_OK;
         if (e == hipSuccess) erc = enqueue_frame(ctx, stream, s, row_begin, row_end, *device_out, flags & ~PAR_RENDER_COUNT_RAYS, true, nullptr);
         hipGraph_t g = nullptr;
         hipError_t e2 = hipStreamEndCapture(stream, &g);
+        hipError_t e3 = hipSuccess;
+        if (e == hipSuccess && erc == PAR_OK && e2 == hipSuccess) {
+            ctx->graph[s] = g;
+            e3 = hipGraphInstantiate(&ctx->graph_exec[s], g, nullptr, nullptr, 0);
+            if (e3 == hipSuccess) continue;
+        } else if (g) {
+            (void)hipGraphDestroy(g);
+        }
+        drop_graphs(ctx);  // never leave one graph of the pair behind
         if (e != hipSuccess) return hip_fail(ctx, e, "graph capture memcpy");
         if (erc != PAR_OK) return erc;
         if (e2 != hipSuccess) return hip_fail(ctx, e2, "hipStreamEndCapture");
-        ctx->graph[s] = g;
-        PAR_HIP(hipGraphInstantiate(&ctx->graph_exec[s], g, nullptr, nullptr, 0));
+        return hip_fail(ctx, e3, "hipGraphInstantiate");
     }
     ctx->graph_set = ctx->set;
     return PAR_OK;
 }
 
-int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, const par_light* light) {
+static int par_graph_stage_impl(par_context* ctx, const par_aabb* aabbs, int first, int n, const par_light* light) {
     if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
     if (n < 0 || first < 0 || first + n > ctx->n_entities || (n > 0 && !aabbs)) return fail(ctx, PAR_ERR_INVALID_ARG, "stage range");
     int64_t total = ctx->total_pairs;
@@ -911,28 +992,48 @@ int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, c
         col_hist(ctx, ctx->h_aabbs[(size_t)(first + i)], -1);
         col_hist(ctx, aabbs[i], +1);
         ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
-        ctx->pin_aabbs[first + i] = aabbs[i];
     }
     ctx->total_pairs = total;
-    if (light) {
-        ctx->light = *light;
-        *ctx->pin_dyn = make_dyn(ctx, *light);
-    }
+    mark_staged(ctx, first, n);  // (the staging areas are brought up to date by par_graph_launch)
+    if (light) ctx->light = *light;
     return PAR_OK;
 }
 
-int par_graph_launch(par_context* ctx, void* stream) {
+static int par_graph_launch_impl(par_context* ctx, void* stream) {
     if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
     // (the scene may also have been changed by par_update_aabbs[_async]: same limit as par_graph_stage)
     if (ctx->total_pairs > ctx->graph_pair_bound) {
         return fail(ctx, PAR_ERR_UNSUPPORTED, "the scene exceeds what the captured graph was sized for; capture again");
     }
-    PAR_HIP(hipGraphLaunch(ctx->graph_exec[ctx->set], (hipStream_t)stream));
+    const int s = ctx->set;
+    if (!ctx->graph_exec[s]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph for this grid set");
+    PAR_HIP(hipSetDevice(ctx->device));
+    // This graph's staging area: free once its previous launch has run (its copy nodes read the area when they
+    // execute, not when the graph is launched), then brought up to date with the host mirror and the light.
+    if (ctx->ev_graph_pending[s]) {
+        PAR_HIP(hipEventSynchronize(ctx->ev_graph[s]));
+        ctx->ev_graph_pending[s] = false;
+    }
+    if (ctx->stage_hi[s] > ctx->stage_lo[s]) {
+        std::memcpy(ctx->pin_aabbs[s] + ctx->stage_lo[s], ctx->h_aabbs.data() + ctx->stage_lo[s],
+                    (size_t)(ctx->stage_hi[s] - ctx->stage_lo[s]) * sizeof(par_aabb));
+        ctx->stage_lo[s] = ctx->stage_hi[s] = 0;
+    }
+    *ctx->pin_dyn[s] = make_dyn(ctx, ctx->light);
+    // an asynchronous scene update on another stream: this frame comes after it
+    if (ctx->ev_update_pending && ctx->update_stream != (hipStream_t)stream) {
+        PAR_HIP(hipStreamWaitEvent((hipStream_t)stream, ctx->ev_update, 0));
+    }
+    PAR_HIP(hipGraphLaunch(ctx->graph_exec[s], (hipStream_t)stream));
+    PAR_HIP(hipEventRecord(ctx->ev_graph[s], (hipStream_t)stream));
+    ctx->ev_graph_pending[s] = true;
     ctx->set ^= 1;
+    ctx->last_stream = (hipStream_t)stream;
+    ctx->has_last_stream = true;
     return PAR_OK;
 }
 
-int par_pick(par_context* ctx, int x, int y, par_pixel* out) {
+static int par_pick_impl(par_context* ctx, int x, int y, par_pixel* out) {
     if (!ctx || !out || x < 0 || y < 0 || x >= ctx->params.width || y >= ctx->params.height) {
         return fail(ctx, PAR_ERR_INVALID_ARG, "pick outside the view");
     }
@@ -944,7 +1045,7 @@ int par_pick(par_context* ctx, int x, int y, par_pixel* out) {
     return PAR_OK;
 }
 
-int par_get_stats(par_context* ctx, par_frame_stats* stats) {
+static int par_get_stats_impl(par_context* ctx, par_frame_stats* stats) {
     if (!ctx || !stats) return fail(ctx, PAR_ERR_INVALID_ARG, "stats");
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
@@ -976,7 +1077,7 @@ int par_debug_read_stamps(par_context* ctx, unsigned long long* out, size_t coun
     return PAR_OK;
 }
 
-int par_read_grid(par_context* ctx, int32_t* count, int32_t* map, par_aabb* bins) {
+static int par_read_grid_impl(par_context* ctx, int32_t* count, int32_t* map, par_aabb* bins) {
     if (!ctx || !count || !map || !bins) return fail(ctx, PAR_ERR_INVALID_ARG, "grid buffers");
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
@@ -996,6 +1097,92 @@ int par_read_grid(par_context* ctx, int32_t* count, int32_t* map, par_aabb* bins
         }
     }
     return PAR_OK;
+}
+
+
+// Test hook: the reference's three arithmetic units as the DEVICE computes them (slab_hit, color_scale,
+// normalize_l1 of par_kernels.hip) on host vectors. See par_raytracer.h.
+static int par_debug_units_impl(int device, int kind, const void* in_a, const void* in_b, int n, void* out) {
+    if (kind < 0 || kind > 2 || n < 0 || !in_a || !out || (kind == 0 && !in_b)) return PAR_ERR_INVALID_ARG;
+    par_context* ctx = nullptr;  // (PAR_HIP reports through it)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PAR_ERR_NO_DEVICE;
+    if (device < 0) device = 0;
+    if (device >= ndev) return PAR_ERR_INVALID_ARG;
+    PAR_HIP(hipSetDevice(device));
+    const size_t a_bytes = (size_t)n * (kind == 0 ? sizeof(par_aabb) : (kind == 1 ? 5 : 3) * sizeof(float));
+    const size_t b_bytes = kind == 0 ? (size_t)n * 20 : 0;
+    const size_t o_bytes = (size_t)n * (kind == 0 ? 1 : (kind == 1 ? 4 : 12));
+    void *da = nullptr, *db = nullptr, *dout = nullptr;
+    hipError_t e = hipMalloc(&da, std::max<size_t>(a_bytes, 16));
+    if (e == hipSuccess) e = hipMalloc(&db, std::max<size_t>(b_bytes, 16));
+    if (e == hipSuccess) e = hipMalloc(&dout, std::max<size_t>(o_bytes, 16));
+    if (e == hipSuccess && a_bytes) e = hipMemcpy(da, in_a, a_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b_bytes) e = hipMemcpy(db, in_b, b_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = par_launch_units(kind, da, db, n, dout, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess && o_bytes) e = hipMemcpy(out, dout, o_bytes, hipMemcpyDeviceToHost);
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    return e == hipSuccess ? PAR_OK : (e == hipErrorOutOfMemory ? PAR_ERR_OOM : PAR_ERR_HIP);
+}
+int par_debug_units(int device, int kind, const void* in_a, const void* in_b, int n, void* out) {
+    return guarded(nullptr, [&] { return par_debug_units_impl(device, kind, in_a, in_b, n, out); });
+}
+
+// ---- the exported entry points of the bodies above: no exception leaves the library -----------------------
+int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) {
+    return guarded(ctx, [&] { return par_set_sprites_impl(ctx, sprites, n_sprites); });
+}
+int par_set_entities(par_context* ctx, const par_aabb* aabbs, const int32_t* sprite_ids, int n) {
+    return guarded(ctx, [&] { return par_set_entities_impl(ctx, aabbs, sprite_ids, n); });
+}
+int par_set_entities_ref_layout(par_context* ctx, const par_aabb* aabbs, const par_sprite* sprite_per_entity, int n) {
+    return guarded(ctx, [&] { return par_set_entities_ref_layout_impl(ctx, aabbs, sprite_per_entity, n); });
+}
+int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n) {
+    return guarded(ctx, [&] { return par_update_aabbs_impl(ctx, aabbs, first, n); });
+}
+int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, int n, void* stream_v) {
+    return guarded(ctx, [&] { return par_update_aabbs_async_impl(ctx, aabbs, first, n, stream_v); });
+}
+int par_pick(par_context* ctx, int x, int y, par_pixel* out) {
+    return guarded(ctx, [&] { return par_pick_impl(ctx, x, y, out); });
+}
+int par_read_grid(par_context* ctx, int32_t* count, int32_t* map, par_aabb* bins) {
+    return guarded(ctx, [&] { return par_read_grid_impl(ctx, count, map, bins); });
+}
+int par_graph_capture(par_context* ctx, void* stream_v, int row_begin, int row_end, const par_outputs* device_out, unsigned flags) {
+    return guarded(ctx, [&] { return par_graph_capture_impl(ctx, stream_v, row_begin, row_end, device_out, flags); });
+}
+int par_graph_stage(par_context* ctx, const par_aabb* aabbs, int first, int n, const par_light* light) {
+    return guarded(ctx, [&] { return par_graph_stage_impl(ctx, aabbs, first, n, light); });
+}
+int par_get_stats(par_context* ctx, par_frame_stats* stats) {
+    return guarded(ctx, [&] { return par_get_stats_impl(ctx, stats); });
+}
+int par_create(const par_params* params, int device, par_context** out) {
+    return guarded(nullptr, [&] { return par_create_impl(params, device, out); });
+}
+
+int par_set_light(par_context* ctx, const par_light* light) {
+    return guarded(ctx, [&] { return par_set_light_impl(ctx, light); });
+}
+int par_render(par_context* ctx, const par_outputs* host_out, unsigned flags) {
+    return guarded(ctx, [&] { return par_render_impl(ctx, host_out, flags); });
+}
+int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outputs* host_out, unsigned flags) {
+    return guarded(ctx, [&] { return par_render_rows_impl(ctx, row_begin, row_end, host_out, flags); });
+}
+int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out, unsigned flags) {
+    return guarded(ctx, [&] { return par_render_device_impl(ctx, stream, row_begin, row_end, device_out, flags); });
+}
+int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out, unsigned flags, par_frame_stats* stats) {
+    return guarded(ctx, [&] { return par_render_device_timed_impl(ctx, stream, row_begin, row_end, device_out, flags, stats); });
+}
+int par_graph_launch(par_context* ctx, void* stream) {
+    return guarded(ctx, [&] { return par_graph_launch_impl(ctx, stream); });
 }
 
 }  // extern "C"

@@ -305,6 +305,14 @@ __device__ __forceinline__ uint32_t color_scale(uint32_t c, float v) {
     return r | (g << 8) | (b << 16) | (c & 0xFF000000u);
 }
 
+// Vector<float>::normalize, spr:28-35: divides by the L1 length (abs(x) + abs(y)) + abs(z).
+__device__ __forceinline__ void normalize_l1(float x, float y, float z, float& nx, float& ny, float& nz) {
+    const float len = __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z);
+    nx = x / len;
+    ny = y / len;
+    nz = z / len;
+}
+
 // Trunc-toward-zero division by the bin size through a precomputed reciprocal: exact for |n| * B < 2^32
 // (|n| <= 3 * 32767 here and B <= 320).
 __device__ __forceinline__ int div_bin(int n, uint32_t magic) {
@@ -667,8 +675,8 @@ __global__ __launch_bounds__(256) void bgline_kernel(par_grid_dev g, par_render_
     const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
     // towards_light = normalize_L1(light - (x, 0, 0)), alt:711-715 + spr:28-35
     const float dx = (float)(dyn.lx - x), dy = (float)(dyn.ly - 0), dz = (float)(dyn.lz - 0);
-    const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
-    const float tx = dx / len, ty = dy / len, tz = dz / len;
+    float tx, ty, tz;
+    normalize_l1(dx, dy, dz, tx, ty, tz);
     const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
     const int ox = (int)(int16_t)x;                                    // alt:720-722
     const int bx = div_bin(x, a.magic_b), sy = a.H / a.B;              // alt:724-727
@@ -1057,8 +1065,8 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         const int wx = col, wy = p_y, wz = p_z;  // alt:707-709
         // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
         const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
-        const float len = __builtin_fabsf(dx) + __builtin_fabsf(dy) + __builtin_fabsf(dz);
-        const float tx = dx / len, ty = dy / len, tz = dz / len;
+        float tx, ty, tz;
+        normalize_l1(dx, dy, dz, tx, ty, tz);
         inv_x = 1.f / tx; inv_y = 1.f / ty; inv_z = 1.f / tz;              // alt:717-719
         const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
         const float diffuse = std_max(0.f, dot);                           // alt:745
@@ -1364,6 +1372,37 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_
     }
 }
 
+// Test hook (par_debug_units): the device functions of the reference's three arithmetic units on caller-supplied
+// vectors, one element per thread. kind 0: AABB::intersect alt:40-83 (a: par_aabb, b: {float inv[3]; int16 origin[3]}
+// -> u8 hit); 1: Color::operator* spr:8-16 (a: float r, g, b, a, v -> u8[4]); 2: Vector::normalize spr:28-35
+// (a: float[3] -> float[3]).
+struct unit_ray {
+    float inv_x, inv_y, inv_z;
+    int16_t ox, oy, oz, pad;
+};
+__global__ __launch_bounds__(256) void units_kernel(int kind, const void* in_a, const void* in_b, int n, void* out) {
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= n) return;
+    if (kind == 0) {
+        const par_aabb box = static_cast<const par_aabb*>(in_a)[i];
+        const unit_ray ray = static_cast<const unit_ray*>(in_b)[i];
+        par_slot rec;
+        rec.px = box.px; rec.py = box.py; rec.pz = box.pz;
+        rec.ex = box.ex; rec.ey = box.ey; rec.ez = box.ez;
+        rec.entity = 0;
+        static_cast<uint8_t*>(out)[i] = slab_hit(rec, ray.ox, ray.oy, ray.oz, ray.inv_x, ray.inv_y, ray.inv_z) ? 1 : 0;
+    } else if (kind == 1) {
+        const float* v = static_cast<const float*>(in_a) + (size_t)i * 5;
+        const uint32_t c = (uint32_t)(uint8_t)v[0] | ((uint32_t)(uint8_t)v[1] << 8) | ((uint32_t)(uint8_t)v[2] << 16) |
+                           ((uint32_t)(uint8_t)v[3] << 24);
+        static_cast<uint32_t*>(out)[i] = color_scale(c, v[4]);
+    } else {
+        const float* v = static_cast<const float*>(in_a) + (size_t)i * 3;
+        float* o = static_cast<float*>(out) + (size_t)i * 3;
+        normalize_l1(v[0], v[1], v[2], o[0], o[1], o[2]);
+    }
+}
+
 }  // namespace
 
 // The fill rides along with the first three launches when it needs only the streaming kernel (frame and
@@ -1580,5 +1619,11 @@ hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_ar
     // overflowed columns are the exception: a small strided grid (up to 8 workgroups share a column)
     const int64_t oblocks = a.dense ? (bound < 1024 ? bound : 1024) : (bound < 32 ? bound : 32);
     hipLaunchKernelGGL(render_overflow_kernel, dim3((unsigned)oblocks, 8u), dim3(PAR_WAVE_NW * 64), 0, stream, g, a);
+    return hipGetLastError();
+}
+
+hipError_t par_launch_units(int kind, const void* in_a, const void* in_b, int n, void* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(units_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, kind, in_a, in_b, n, out);
     return hipGetLastError();
 }

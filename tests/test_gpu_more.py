@@ -315,34 +315,116 @@ def test_edge_views_and_lights(par, oracle, sprite, T):
 
 
 def test_config5_scale_animation(par, oracle, sprite, T):
-    """BASELINE config 5 at its own size: 1024x1024, 512 moving primitives, hipGraph replay per frame (a sample of
-    frames checked against the oracle; positions keep moving by the reference's step of 5, alt:643-678)."""
+    """BASELINE config 5 at its own size: 1024x1024, 512 moving primitives, hipGraph replay per frame with the frames
+    IN FLIGHT (no host wait between stage and launch: a graph's copy nodes read its staging area when the graph runs,
+    so frame f + 1 must not be staged over frame f). Every frame is copied out in stream order and compared with a
+    second renderer's blocking render of the same scene; every 10th also with the oracle. Positions keep moving by
+    the reference's step of 5 (alt:643-678); the light moves through par_set_light as well as par_graph_stage."""
     import os
     import torch
     w = h = l = 1024
     n = 512
+    frames = 60
     params = T.default_params(w, h, l)
     aabbs, light = par.scene_synthetic(n, w, h, l, 99)
     rng = np.random.default_rng(11)
     vel = rng.choice([-5, 0, 5], size=(n, 3)).astype(np.int16)
     fb = torch.zeros(w * h * 4, dtype=torch.uint8, device="cuda")
+    ring = torch.zeros(frames, w * h * 4, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.Stream()
-    with par.Renderer(params) as r:
+    scenes = []
+    with par.Renderer(params) as r, par.Renderer(params) as check:
         r.set_scene(aabbs, sprite, light)
+        check.set_scene(aabbs, sprite, light)
         r.graph_capture({"fb": fb.data_ptr()}, stream=stream.cuda_stream)
-        for f in range(40):
+        for f in range(frames):
             if f:
                 aabbs["px"] += vel[:, 0]
                 aabbs["py"] += vel[:, 1]
                 aabbs["pz"] += vel[:, 2]
                 if f % 7 == 0:
                     light["z"] += 5
-                r.graph_stage(aabbs, 0, light)
+                if f % 14 == 0:
+                    r.graph_stage(aabbs, 0)
+                    r.set_light(light)       # the light alone, outside the stage call
+                else:
+                    r.graph_stage(aabbs, 0, light)
             r.graph_launch(stream.cuda_stream)
-            if f % 8 == 0 or f == 39:
-                stream.synchronize()
-                exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb",))
-                assert np.array_equal(fb.cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
+            with torch.cuda.stream(stream):
+                ring[f].copy_(fb, non_blocking=True)
+            scenes.append((aabbs.copy(), light.copy()))
+        stream.synchronize()
+        got = ring.cpu().numpy()
+        for f, (a, li) in enumerate(scenes):
+            check.update_aabbs(a, 0)
+            check.set_light(li)
+            exp = check.render(("fb",))["fb"].view(np.uint8)
+            assert np.array_equal(got[f], exp), f"frame {f}: graph replay with frames in flight"
+            if f % 10 == 0 or f == frames - 1:
+                ora = oracle.render(params, a, sprite, li, nthreads=os.cpu_count() or 8, planes=("fb",))
+                assert np.array_equal(got[f], ora["fb"].view(np.uint8)), f"frame {f} vs oracle"
+
+
+def test_config5_full_run_frames_in_flight(par, oracle, sprite, T):
+    """BASELINE config 5 for its full 300 frames through the frames-in-flight path: four slots, every slot's context
+    gets the frame's AABBs in stream order (par_update_aabbs_async) before it renders; every 25th frame (and the
+    last) is compared with the oracle."""
+    import importlib
+    import os
+    import torch
+    pipeline = importlib.import_module("pixel-art-raytracer_amd.pipeline")
+    w = h = l = 1024
+    n = 512
+    params = T.default_params(w, h, l)
+    aabbs0, light = par.scene_synthetic(n, w, h, l, 77)
+    rng = np.random.default_rng(5)
+    vel = rng.choice([-5, 0, 5], size=(n, 3)).astype(np.int16)
+    pipe = pipeline.FramePipeline(params, aabbs0, sprite, light, depth=4, planes=("fb", "palidx"), calibrate=False)
+    try:
+        for f in range(300):
+            a = aabbs0.copy()
+            a["px"] += vel[:, 0] * f
+            a["py"] += vel[:, 1] * f
+            a["pz"] += vel[:, 2] * f
+            pipe.update_aabbs(f, a)
+            slot = pipe.submit(f)
+            if f % 25 == 0 or f == 299:
+                slot.stream.synchronize()
+                exp = oracle.render(params, a, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb", "palidx"))
+                assert np.array_equal(slot.buffers["fb"].cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
+                assert np.array_equal(slot.buffers["palidx"].cpu().numpy(), exp["palidx"]), f"frame {f}"
+    finally:
+        pipe.close()
+
+
+def test_graph_is_dropped_with_its_sprite_table_and_reports_allocation_failure(par, sprite, T, monkeypatch):
+    """par_set_sprites frees the tables a captured graph's kernels point at: the graph must be gone afterwards
+    (PAR_ERR_NOT_READY, not a read of freed memory). And a host allocation failure inside the library comes back as
+    PAR_ERR_OOM through the C ABI, never as an exception (PAR_TEST_BAD_ALLOC=1 makes the guarded bodies throw)."""
+    import torch
+    params = T.default_params(256, 256, 256)
+    aabbs, light = par.scene_synthetic(40, 256, 256, 256, 3)
+    fb = torch.zeros(256 * 256 * 4, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.Stream()
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        r.graph_capture({"fb": fb.data_ptr()}, stream=stream.cuda_stream)
+        r.graph_launch(stream.cuda_stream)
+        stream.synchronize()
+        r.set_sprites(sprite)
+        with pytest.raises(par.ParError) as e:
+            r.graph_launch(stream.cuda_stream)
+        assert e.value.status == 8  # PAR_ERR_NOT_READY
+        monkeypatch.setenv("PAR_TEST_BAD_ALLOC", "1")
+        with pytest.raises(par.ParError) as e:
+            r.set_entities(aabbs)
+        assert e.value.status == 4  # PAR_ERR_OOM
+        with pytest.raises(par.ParError) as e:
+            r.set_sprites(sprite)
+        assert e.value.status == 4
+        monkeypatch.delenv("PAR_TEST_BAD_ALLOC")
+        r.set_scene(aabbs, sprite, light)  # the context is still usable
+        assert r.render(("fb",))["fb"].shape[0] == 256 * 256
 
 
 def test_config1_default_scene_128(par, oracle, sprite, T):

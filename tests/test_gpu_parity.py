@@ -1,5 +1,7 @@
 """GPU parity: the HIP path through the C ABI against the CPU oracle and the committed golden vectors. Bit-exact
 on every plane: integer planes (palette index, G-buffer ints, RGBA) and the fp32 brightness plane alike."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,12 +75,13 @@ def test_default_scene_and_script(par, oracle, appendix_b, sprite, T):
             assert sha(fb) == want, f
 
 
+# (512, 512, 512, 64, 12345) is BASELINE config 2 and (2048, 2048, 2048, 256, 12345) config 3, both exactly as stated
 @pytest.mark.parametrize("w,h,l,n,seed", [(128, 128, 128, 40, 3), (512, 512, 512, 64, 12345), (500, 333, 290, 200, 1),
-                                          (1024, 640, 512, 512, 2)])
+                                          (1024, 640, 512, 512, 2), (2048, 2048, 2048, 256, 12345)])
 def test_sizes_vs_oracle(par, oracle, sprite, T, w, h, l, n, seed):
     params = T.default_params(w, h, l)
     aabbs, light = par.scene_synthetic(n, w, h, l, seed)
-    exp = oracle.render(params, aabbs, sprite, light, nthreads=8)
+    exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8)
     with par.Renderer(params) as r:
         r.set_scene(aabbs, sprite, light)
         out = r.render(ALL)
@@ -160,3 +163,20 @@ def test_errors(par, T):
     bad.ambient = 1.5
     with pytest.raises(par.ParError):
         par.Renderer(bad)
+
+
+def test_device_units_equal_the_reference(par, T):
+    """AABB::intersect (alt:40-83), Color::operator* (spr:8-16) and Vector::normalize (spr:28-35) as the DEVICE
+    kernels compute them (slab_hit, color_scale, normalize_l1 through the par_debug_units hook) on the unit vectors
+    tests/golden/ref_units.npz holds, against the answers the reference's own compiled functions gave for them:
+    4 096 + 2 048 + 2 048 results, bit for bit (NaN payloads and +-inf inverse directions included)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_units.npz"))
+    boxes = np.ascontiguousarray(z["boxes"]).view(T.AABB).reshape(-1)
+    rays = np.ascontiguousarray(z["rays"]).view(T.RAY).reshape(-1)
+    assert np.isnan(rays["inv_x"]).any() and np.isinf(rays["inv_y"]).any()
+    hit = par.debug_units(0, boxes, rays)
+    assert np.array_equal(hit, z["hit"])
+    cs = par.debug_units(1, z["cs_in"].astype(np.float32))
+    assert np.array_equal(cs, z["cs_out"])
+    nv = par.debug_units(2, z["nv"].astype(np.float32))
+    assert nv.tobytes() == z["nv_out"].astype(np.float32).tobytes()
