@@ -156,6 +156,8 @@ class Reference:
         L.ref_bin.argtypes = [C.c_void_p] * 4
         L.ref_primary.argtypes = [C.c_void_p] * 5
         L.ref_shade.argtypes = [C.c_void_p] * 8
+        L.ref_shade_own.argtypes = [C.c_void_p] * 6
+        L.ref_debug_line_own.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ref_shadow.restype = C.c_int
         L.ref_shadow.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]
         L.ref_intersect.restype = C.c_int
@@ -223,7 +225,19 @@ class Reference:
                                        *[int(v) for v in start], *[int(v) for v in end], int(start_entity),
                                        T.ptr(ray)))
 
+    def shade_own(self, grid, gbuf, light):
+        """The reference's OWN inline loop, alt:702-760 (compiled from where it lies): the RGBA frame."""
+        fb = np.zeros(self.consts["width"] * self.consts["height"], dtype=T.COLOR)
+        self.lib.ref_shade_own(T.ptr(grid.count), T.ptr(grid.map), T.ptr(grid.bins), T.ptr(gbuf), T.ptr(light),
+                               T.ptr(fb))
+        return fb
+
+    def debug_line_own(self, pick, mouse_x, mouse_y, light, fb):
+        """The reference's OWN debug-line call, alt:763-772, drawn into `fb`."""
+        self.lib.ref_debug_line_own(T.ptr(pick), int(mouse_x), int(mouse_y), T.ptr(light), T.ptr(fb))
+
     def shade(self, grid, gbuf, light):
+        """A replay of alt:702-760 around the reference's own callees that also returns brightness and lit."""
         n = self.consts["width"] * self.consts["height"]
         fb = np.zeros(n, dtype=T.COLOR)
         br = np.zeros(n, dtype=np.float32)

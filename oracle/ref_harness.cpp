@@ -5,10 +5,14 @@
 // constants, count_entities_in_bins, trace_hash_for_pixel, trace_hash_for_light, AABB::intersect — none of which
 // touch SDL) into the compiler from where they lie, followed by this file, and writes only
 // oracle/_ref/libref_path.so. No reference source is copied into the repository and no stand-in for the absent
-// SDL2 headers is written; the reference's `main` (window, input, blit — and the inline shading loop
-// alt:702-760) is therefore NOT part of this build. `ref_shade` below replays that loop around the reference's
-// own trace_hash_for_light / Vector::normalize / Color::operator* so the tests can pin the oracle's shading;
-// the whole-program known answers of SURVEY Appendix B pin it independently.
+// SDL2 headers is written; the reference's `main` (window, input, blit) is therefore NOT part of this build.
+// Its inline shading loop (alt:702-760) and its debug-line call (alt:763-772), which use no SDL symbol, ARE: the
+// Makefile streams those lines, from where they lie, into the bodies of `ref_shade_own` and `ref_debug_line_own`
+// at the two marker lines below; the parameters and locals there carry the names the reference's lines use
+// (p_pixel_buffer, p_texture, lights, p_aabb_count_in_bin, p_aabb_bins, p_aabb_index_to_entity_index_map,
+// mouse_pixel). `ref_shade` further down is a REPLAY of the same loop around the reference's own callees that also
+// hands out the brightness and lit planes, which the reference's loop keeps in locals; the tests hold the two
+// against each other. The whole-program known answers of SURVEY Appendix B pin all of it independently.
 #include <cstring>
 
 #include "par_types.h"
@@ -138,6 +142,33 @@ void ref_shade(int* count, int* map, par_aabb* bins, const par_pixel* gbuf_in, c
         if (brightness) brightness[i] = b;
         if (lit_plane) lit_plane[i] = lit ? 1 : 0;
     }
+}
+
+// The reference's OWN shading loop, alt:702-760, compiled from where it lies (see the Makefile): the final RGBA
+// frame from a G-buffer. The light must keep every probed flat bin index inside [0, hash_volume), as for ref_shade.
+void ref_shade_own(int* p_aabb_count_in_bin, int* p_aabb_index_to_entity_index_map, par_aabb* bins_in,
+                   const par_pixel* gbuf_in, const par_light* light_in, par_color* fb) {
+    AABB* p_aabb_bins = reinterpret_cast<AABB*>(bins_in);
+    // (the loop binds `Pixel& this_pixel` and only reads through it)
+    Pixel* p_pixel_buffer = const_cast<Pixel*>(reinterpret_cast<const Pixel*>(gbuf_in));
+    Color* p_texture = reinterpret_cast<Color*>(fb);
+    const par_light lights[1] = {*light_in};
+// @@REFERENCE alt:702-760@@
+}
+
+// The reference's OWN debug-line call, alt:763-772: Bresenham from the picked texel's screen position to the
+// light's, drawn into the frame (`draw_line` itself, alt:139-175, is part of lines 2-500).
+void ref_debug_line_own(const par_pixel* pick, int mouse_x_in, int mouse_y_in, const par_light* light_in,
+                        par_color* fb) {
+    Color* p_texture = reinterpret_cast<Color*>(fb);
+    const par_light lights[1] = {*light_in};
+    Pixel picked;
+    std::memcpy(&picked, pick, sizeof(picked));
+    mouse_pixel = &picked;
+    mouse_x = mouse_x_in;
+    mouse_y = mouse_y_in;
+// @@REFERENCE alt:763-772@@
+    mouse_pixel = nullptr;
 }
 
 }  // extern "C"

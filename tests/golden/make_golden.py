@@ -104,7 +104,10 @@ def frames(ref):
         grid = GridArrays(ref.params())
         ref.bin(h, grid)
         gbuf = ref.primary(h, grid)
-        fb, br, lit = ref.shade(grid, gbuf, light)
+        fb, br, lit = ref.shade(grid, gbuf, light)   # replay: also brightness and lit, which the loop keeps in locals
+        own = ref.shade_own(grid, gbuf, light)       # the reference's own loop, alt:702-760: the frame the hash is of
+        assert own.tobytes() == fb.tobytes(), name
+        fb = own
         ref.scene_free(h)
         arrays[name + "_aabbs"] = aabbs.view(np.int16).reshape(-1, 8)
         arrays[name + "_light"] = light.view(np.int16)

@@ -40,8 +40,11 @@ def test_random_scenes_all_stages(oracle, reference, T, seed):
     gb_or, _ = oracle.primary(params, g_or, oracle.tile_floor())
     assert gb_ref.tobytes() == gb_or.tobytes()
     fb_ref, br_ref, lit_ref = reference.shade(g_ref, gb_ref, light)
+    fb_own = reference.shade_own(g_ref, gb_ref, light)  # the reference's own loop, alt:702-760
     fb_or, br_or, lit_or = oracle.shade(params, g_or, gb_or, light)
     reference.scene_free(h)
+    assert fb_own.tobytes() == fb_or.tobytes()
+    assert fb_own.tobytes() == fb_ref.tobytes()
     assert fb_ref.tobytes() == fb_or.tobytes()
     assert br_ref.tobytes() == br_or.tobytes()
     assert lit_ref.tobytes() == lit_or.tobytes()
@@ -70,3 +73,29 @@ def test_shadow_walk_direct(oracle, reference, T):
         ray["ox"], ray["oy"], ray["oz"] = rng.integers(0, 480), rng.integers(0, 200), rng.integers(0, 320)
         ent = int(rng.integers(0, n))
         assert oracle.shadow(g, s, e, ent, ray) == reference.shadow(g, s, e, ent, ray)
+
+
+def test_reference_own_shading_loop_on_the_golden_frames(oracle, reference, golden_frames, T):
+    """alt:702-760 and alt:763-772 compiled from where they lie (ref_shade_own / ref_debug_line_own): the RGBA frame
+    of every golden case equals the committed hash (which make_golden.py took from the same functions), the
+    oracle's frame and the harness replay's; the debug line equals the oracle's restatement of it."""
+    from helpers import sha
+    params = reference.params()
+    sprite = oracle.tile_floor()
+    for name, (m, aabbs, light) in golden_frames.items():
+        h = reference.scene(aabbs)
+        g = GridArrays(params)
+        reference.bin(h, g)
+        gbuf = reference.primary(h, g)
+        own = reference.shade_own(g, gbuf, light)
+        replay, _, _ = reference.shade(g, gbuf, light)
+        reference.scene_free(h)
+        assert sha(own) == m["fb"], name
+        assert own.tobytes() == replay.tobytes(), name
+        assert own.tobytes() == oracle.render(params, aabbs, sprite, light, planes=("fb",))["fb"].tobytes(), name
+        a, b = own.copy(), own.copy()
+        for mx, my in [(0, 0), (240, 160), (479, 319)]:
+            pick = gbuf[my * 480 + mx:my * 480 + mx + 1]
+            reference.debug_line_own(pick, mx, my, light, a)
+            oracle.debug_line(params, gbuf, light, mx, my, b)
+            assert a.tobytes() == b.tobytes(), (name, mx, my)
