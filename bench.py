@@ -8,12 +8,17 @@
 A step = one frame of the hot path (alt:690-760 of the reference): rebuild the spatial hash from the resident
 AABBs, cast one primary and one shadow ray per pixel, shade, quantise — writing the RGBA8 frame and the
 palette-index plane. Scene, sprites and output buffers are resident in HBM before the timed region. With N > 1 the
-same frame is sharded by row block (rank r renders rows [H r/N, H (r+1)/N)) and the blocks are gathered to rank 0
-with one RCCL gather per frame (strong scaling: total work is fixed as N grows).
+same frame is sharded by row block (cut at bin rows, pixel-art-raytracer_amd/sharding.py) and the blocks are gathered
+to rank 0 with one RCCL gather per frame (strong scaling: total work is fixed as N grows).
 
 Frames in flight: like a swap chain, `--inflight` (default 4) frames are in flight at once, each with its own context,
 stream and output buffers (pixel-art-raytracer_amd/pipeline.py); one frame alone is a chain of short latency-bound
-kernels that leaves most of the chip idle. `--inflight 1` gives the one-frame-at-a-time rate.
+kernels that leaves most of the chip idle. `value` is therefore a RATE with 4 frames in flight; the latency of one
+frame on its own is reported beside it (`one_frame_at_a_time`).
+
+Timing: W untimed warm-up steps (after a time-based clock ramp), then BLOCKS (30) blocks of exactly K steps, each
+bracketed by a barrier + torch.cuda.synchronize() on both sides; `ms_per_step` is the MEDIAN block's time / K (the
+spread over the blocks is reported too), with N > 1 the maximum over ranks of each block first.
 
 Mrays/s is nominal = 2 * W * H * frames / seconds (the reference casts exactly one primary and one shadow ray per
 pixel, background included: alt:277-279, 703, 738). The GPU path skips the shadow ray of background pixels, whose
@@ -26,6 +31,7 @@ import argparse
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -39,27 +45,34 @@ W = H = L = 4096
 N_PRIMS = 1024
 SEED = 12345
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BLOCKS = 30
+ORACLE_ROWS = (3 * 4096 // 8, 5 * 4096 // 8)  # the band of the frame the CPU baseline renders (and the GPU is checked on)
 
 
-def cpu_baseline(par, T, params, aabbs, light, sprite, rows):
+def cpu_baseline(params, aabbs, light, sprite, rows, gpu_fb, gpu_pal):
     """Oracle (our CPU restatement of the reference, pinned to it) on the host cores: a bounded sample of the same
-    workload — the row band `rows` of the same 4096x4096 frame, single thread, as the reference runs."""
+    workload — the row band `rows` of the same frame, single thread, as the reference runs. The band it renders is
+    also what the GPU frame is checked against (`verified`)."""
     from oracle.oracle import Oracle
-    import statistics
     o = Oracle()
     grid = o.bin(params, aabbs)
     r0, r1 = rows
+    w = params.width
+    band = {}
 
-    def band():
+    def run():
         t0 = time.perf_counter()
-        gbuf, _ = o.primary(params, grid, sprite, rows=rows)
-        o.shade(params, grid, gbuf, light, rows=rows)
+        gbuf, pal = o.primary(params, grid, sprite, rows=rows)
+        fb, _, _ = o.shade(params, grid, gbuf, light, rows=rows)
+        band["fb"], band["pal"] = fb, pal
         return time.perf_counter() - t0
 
-    band()  # warm-up, excluded
-    times = [band() for _ in range(5)]
+    run()  # warm-up, excluded
+    times = [run() for _ in range(5)]
     dt = statistics.median(times)
-    single = 2.0 * (r1 - r0) * params.width / dt / 1e6
+    single = 2.0 * (r1 - r0) * w / dt / 1e6
+    verified = bool(np.array_equal(band["fb"][r0 * w:r1 * w].view(np.uint8), gpu_fb[r0 * w * 4:r1 * w * 4]) and
+                    np.array_equal(band["pal"][r0 * w:r1 * w], gpu_pal[r0 * w:r1 * w]))
     ncores = os.cpu_count() or 1
 
     def whole():
@@ -77,17 +90,87 @@ def cpu_baseline(par, T, params, aabbs, light, sprite, rows):
         "all_cores": {"value": round(2.0 * params.width * params.height / dt_all / 1e6, 3), "cores": ncores,
                       "sample": f"whole frame, rows split over {ncores} threads, median of 3 ({dt_all:.2f} s each); "
                                 "ours, not the reference's"},
-    }
+    }, verified
+
+
+def time_blocks(run_block, steps, blocks, barrier, reduce_max):
+    """`blocks` blocks of exactly `steps` steps, each bracketed by barrier + synchronize; per block the maximum over
+    ranks. Returns the per-step times (ms) of the blocks."""
+    out = []
+    first = 0
+    for _ in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        run_block(first, steps)
+        barrier()
+        out.append(reduce_max(time.perf_counter() - t0) / steps * 1e3)
+        first += steps
+    return out
+
+
+def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, depth, steps):
+    """An extra workload beside the headline (same code path, same harness): rate with `depth` frames in flight, one
+    frame at a time, and the kernel groups of one frame timed apart."""
+    import torch
+    w, h = params.width, params.height
+    pipe = pipeline.FramePipeline(params, aabbs, sprite, light, depth=depth, device=device, planes=("fb", "palidx"))
+    try:
+        pipe.submit_many(0, 4 * depth)
+        pipe.synchronize()
+        ms = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pipe.submit_many(0, steps)
+            pipe.synchronize()
+            ms.append((time.perf_counter() - t0) / steps * 1e3)
+        per = statistics.median(ms)
+        r = pipe.slots[0].renderer
+        ptrs = pipe.slots[0].ptrs
+        stream = torch.cuda.current_stream().cuda_stream
+        for _ in range(5):
+            r.render_device(ptrs, stream=stream)
+        torch.cuda.synchronize()
+        n1 = max(20, steps // 4)
+        t0 = time.perf_counter()
+        for _ in range(n1):
+            r.render_device(ptrs, stream=stream)
+        torch.cuda.synchronize()
+        alone = (time.perf_counter() - t0) / n1 * 1e3
+        parts = {"hash_build+columns": [], "fill_kernel": [], "render_items_kernel": [], "render_overflow_kernel": []}
+        for i in range(13):
+            st = r.render_device(ptrs, stream=stream, timed=True)
+            if i >= 3:
+                parts["hash_build+columns"].append(st.ms_bin)
+                parts["fill_kernel"].append(st.ms_fill)
+                parts["render_items_kernel"].append(st.ms_render)
+                parts["render_overflow_kernel"].append(st.ms_overflow)
+        stats = r.stats()
+        full = r.render(("palidx",))
+        covered = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
+        return {
+            "workload": name, "ms_per_frame": round(per, 5), "frames_in_flight": depth,
+            "mrays_per_s": round(2.0 * w * h / per / 1e3, 1),
+            "hbm_frac": round(5.0 * w * h / (per * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "one_frame_at_a_time_ms": round(alone, 5),
+            "kernels_ms_one_at_a_time": {k: round(float(np.mean(v)), 5) for k, v in parts.items()},
+            "covered_pixels": covered, "pixels": w * h, "entities": int(stats.entities),
+            "occupied_columns": int(stats.occupied_columns), "overflow_columns": int(stats.overflow_columns),
+        }
+    finally:
+        pipe.close()
 
 
 def main():
     global W, H, L, N_PRIMS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--blocks", type=int, default=BLOCKS, help="timed blocks of --steps steps (median reported)")
     ap.add_argument("--inflight", type=int, default=4, help="frames in flight (contexts/streams/buffers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dense / default-scene side measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="tests: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--size", type=int, default=W, help="view size (the headline benchmark is 4096; BASELINE config 3: 2048)")
@@ -96,6 +179,7 @@ def main():
 
     W = H = L = args.size
     N_PRIMS = args.prims
+    os.environ.setdefault("PAR_DEBUG_STAMPS", "1")  # allocates the stamp buffers; stamps are taken on request only
     import torch
     import torch.distributed as dist
 
@@ -120,35 +204,34 @@ def main():
     par = importlib.import_module("pixel-art-raytracer_amd")
     T = par.types
     sharding = importlib.import_module("pixel-art-raytracer_amd.sharding")
+    pipeline = importlib.import_module("pixel-art-raytracer_amd.pipeline")
 
     params = T.default_params(W, H, L)
     aabbs, light = par.scene_synthetic(N_PRIMS, W, H, L, SEED)
     sprite = par.tile_floor()
-    pipeline = importlib.import_module("pixel-art-raytracer_amd.pipeline")
 
-    r0, r1 = sharding.row_block(rank, world, H)
+    r0, r1 = sharding.row_block(rank, world, H, params.bin_size)
+    has_rows = r1 > r0
     gather = None
     rows_alloc = H
     if world > 1:
-        gather = sharding.FrameGather(H, W * 4, torch.uint8, dev, world, rank)
-        rows_alloc = gather.max_rows
+        gather = sharding.FrameGather(H, W * 4, torch.uint8, dev, world, rank, bin_size=params.bin_size)
+        rows_alloc = max(gather.max_rows, 1)
     depth = max(1, args.inflight)
-    pipe = pipeline.FramePipeline(params, aabbs, sprite, light, depth=depth, device=local_rank, rows=(r0, r1),
-                                  planes=("fb", "palidx"), rows_alloc=rows_alloc)
+    pipe = pipeline.FramePipeline(params, aabbs, sprite, light, depth=depth, device=local_rank,
+                                  rows=(r0, r1) if has_rows else (0, 1), planes=("fb", "palidx"), rows_alloc=rows_alloc)
     r = pipe.slots[0].renderer
     fb = [s_.buffers["fb"] for s_ in pipe.slots]
     pal = [s_.buffers["palidx"] for s_ in pipe.slots]
 
-    def step(i, flags=0):
+    def step(i, flags=0):  # N > 1: render + gather per frame (the interpreter is not what bounds that path)
         slot = pipe.slot(i)
-        if gather is None:
-            pipe.submit(i, flags)
-            return
         with torch.cuda.stream(slot.stream):  # the collective is ordered after the render on the slot's stream
             if slot.pending is not None:      # the gather that last read this slot's block buffer
                 slot.pending.wait()
                 slot.pending = None
-            pipe.submit(i, flags)
+            if has_rows:
+                pipe.submit(i, flags)
             slot.pending = gather.gather(slot.buffers["fb"], async_op=True)
 
     def drain():
@@ -162,50 +245,67 @@ def main():
             gather.unpack()
         torch.cuda.synchronize()
 
+    def run_block(first, n, flags=0):
+        """Exactly n steps, drained."""
+        if gather is None:
+            pipe.submit_many(first, n, flags)  # the swap chain's loop runs in the library, one call
+        else:
+            for i in range(first, first + n):
+                step(i, flags)
+        drain()
+
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # correctness of what is about to be timed (before the warm-up, so that the GPU does not idle between warm-up
-    # and the timed region): rank 0 renders the whole frame alone and compares
-    for i in range(depth):
-        step(i)
-    drain()
-    verified = None
+    def reduce_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # correctness of what is about to be timed: the frames in flight against one blocking whole-frame render
+    run_block(0, depth)
+    verified_gpu = None
+    hit_pixels = 0
+    full = None
     if rank == 0:
         full = r.render(("fb", "palidx"))
         if world > 1:
-            verified = bool(np.array_equal(gather.frame.cpu().numpy(), full["fb"].view(np.uint8)))
+            verified_gpu = bool(np.array_equal(gather.frame.cpu().numpy(), full["fb"].view(np.uint8)))
         else:
-            verified = all(bool(np.array_equal(fb[k].cpu().numpy(), full["fb"].view(np.uint8)) and
-                                np.array_equal(pal[k].cpu().numpy(), full["palidx"])) for k in range(depth))
+            verified_gpu = all(bool(np.array_equal(fb[k].cpu().numpy(), full["fb"].view(np.uint8)) and
+                                    np.array_equal(pal[k].cpu().numpy(), full["palidx"])) for k in range(depth))
         hit_pixels = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
     barrier()
 
-    # warm-up (untimed)
-    for i in range(args.warmup):
-        step(i)
-    drain()
+    # clock ramp (time-based, untimed): the GPU's clocks and the host's caches settle before anything is counted
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 0.6:
+        run_block(0, 4 * depth)
+    # warm-up (untimed, counted)
+    run_block(0, max(args.warmup, 1))
 
-    # timed region: exactly K steps
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    drain()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # timed region: BLOCKS blocks of exactly K steps
+    per_step = time_blocks(run_block, args.steps, max(1, args.blocks), barrier, reduce_max)
+    ms_per_step = statistics.median(per_step)
+
+    # the frame's kernels while the timed configuration runs: workgroup time stamps of `depth` frames in mid-flight
+    kernels_pipelined = None
+    if world == 1:
+        pipe.submit_many(0, 6 * depth)
+        pipe.submit_many(6 * depth, depth, 1 << 29)
+        pipe.submit_many(7 * depth, 6 * depth)
+        drain()
+        kernels_pipelined = pipe.kernel_spans_us()
 
     out = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
         rays_per_frame = 2.0 * W * H
-        value = rays_per_frame * args.steps / elapsed / 1e6
+        value = rays_per_frame / (ms_per_step * 1e-3) / 1e6
+        srt = sorted(per_step)
         out = {
             "metric": f"Mrays/sec at {W}x{H}, {N_PRIMS} prims", "value": round(value, 1), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5),
@@ -213,28 +313,74 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{W}x{H}x{L} view, bin 40, {N_PRIMS} primitives (splitmix64 seed {SEED}), "
                                    f"light ({5 * W // 8},{H // 2},{L // 4}); RGBA8 frame + palette-index plane",
-                       "sharding": f"row blocks over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
-                       "frames_in_flight": depth, "streams_overlap_pairwise": bool(pipe.streams_overlap)},
-            "frames_per_s": round(args.steps / elapsed, 1),
-            "mpix_per_s": round(W * H * args.steps / elapsed / 1e6, 1),
+                       "sharding": f"row blocks over {world} GPU(s), cut at bin rows" +
+                                   (", RCCL gather to rank 0" if world > 1 else ""),
+                       "frames_in_flight": depth, "streams_overlap_pairwise": bool(pipe.streams_overlap),
+                       "note": "value is a rate with frames_in_flight frames in flight; one_frame_at_a_time is the "
+                               "latency of a frame on its own"},
+            "ms_per_step_spread": {"blocks": len(per_step), "min": round(srt[0], 5), "p10": round(srt[len(srt) // 10], 5),
+                                   "median": round(ms_per_step, 5), "p90": round(srt[(9 * len(srt)) // 10], 5),
+                                   "max": round(srt[-1], 5), "mean": round(statistics.fmean(per_step), 5)},
+            "frames_per_s": round(1e3 / ms_per_step, 1),
+            "mpix_per_s": round(W * H / ms_per_step / 1e3, 1),
             "rays": {"nominal_per_frame": int(rays_per_frame), "traced_per_frame": int(W * H + hit_pixels),
                      "note": "shadow rays of background pixels are output-neutral and skipped"},
-            "verified_vs_single_gpu_frame": verified,
+            "verified_vs_single_gpu_frame": verified_gpu,
         }
+        if kernels_pipelined:
+            out["kernels_ms_pipelined"] = {k: round(v / 1e3, 5) for k, v in kernels_pipelined.items()}
+            out["kernels_ms_pipelined"]["note"] = ("first workgroup start to last workgroup end of each launch of one "
+                                                   "frame, mean over the frames in flight, from GPU time stamps taken "
+                                                   "while the timed configuration runs (no profiler)")
+
+    # ---- N > 1: where a frame's time goes on this rank, and who took part -----------------------------------
+    if world > 1:
+        slot = pipe.slots[0]
+        reps = 20
+        drain()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            if has_rows:
+                pipe.submit(0)
+            slot.stream.synchronize()
+        render_ms = (time.perf_counter() - t0) / reps * 1e3
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            with torch.cuda.stream(slot.stream):
+                w_ = gather.gather(slot.buffers["fb"], async_op=True)
+                w_.wait()
+            slot.stream.synchronize()
+        gather_ms = (time.perf_counter() - t0) / reps * 1e3
+        names = [None] * world
+        dist.all_gather_object(names, f"rank {rank}: {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank}), "
+                                      f"rows {r0}..{r1}")
+        worst_render = reduce_max(render_ms)
+        if rank == 0:
+            out["multi_gpu"] = {
+                "render_ms": round(worst_render, 5), "gather_ms": round(gather_ms, 5),
+                "gather_bytes_per_rank": int(gather.max_rows * W * 4), "ranks_seen": names,
+                "note": "render_ms: one frame's row block rendered and waited for, one at a time (maximum over ranks); "
+                        "gather_ms: one gather of the blocks to rank 0 on its own, waited for; the timed region "
+                        "overlaps both over the frames in flight",
+            }
 
     # ---- roofline of the dominant kernel + the all-rays-traced rate (N = 1 only; untimed extras) -------------
     if world == 1:
         ptrs = {"fb": fb[0].data_ptr(), "palidx": pal[0].data_ptr()}
         stream = torch.cuda.current_stream().cuda_stream
         # one frame at a time (no other frame in flight): the latency of a frame and its kernels
-        for i in range(20):
+        for i in range(50):
             r.render_device(ptrs, stream=stream)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(200):
-            r.render_device(ptrs, stream=stream)
-        torch.cuda.synchronize()
-        out["one_frame_at_a_time"] = {"ms_per_frame": round((time.perf_counter() - t0) / 200 * 1e3, 5)}
+        lat = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            for i in range(200):
+                r.render_device(ptrs, stream=stream)
+            torch.cuda.synchronize()
+            lat.append((time.perf_counter() - t0) / 200 * 1e3)
+        out["one_frame_at_a_time"] = {"ms_per_frame": round(statistics.median(lat), 5)}
         ms = {"bin": [], "fill": [], "render": [], "overflow": []}
         for _ in range(5):
             r.render_device(ptrs, stream=stream, timed=True)
@@ -248,34 +394,40 @@ def main():
         ncols = int(r.stats().occupied_columns)
         gx, gy, gz = params.grid_dims()
         # Algorithmic bytes: 2.5 B per nominal ray = 5 B per pixel (4 B RGBA8 + 1 B palette index; two
-        # rays per pixel). fill_kernel writes every pixel of the frame once (5 B x W x H); render_wave_kernel then
+        # rays per pixel). The fill writes every pixel of the frame once (5 B x W x H); render_items_kernel then
         # writes the pixels primitives cover (5 B x covered pixels) - the only bytes that kernel has to move.
         bytes_frame = 2.5 * 2.0 * W * H
         bytes_render = 5.0 * hit_pixels
-        kernels = {"render_wave_kernel": (avg["render"], bytes_render), "fill_kernel": (avg["fill"], bytes_frame)}
-        dominant = max(kernels, key=lambda k: kernels[k][0])
+        kernels = {"render_items_kernel": (avg["render"], bytes_render), "fill_kernel": (avg["fill"], bytes_frame)}
+        dominant = "render_items_kernel"  # of the three launches of a production frame, the longest
         dom_ms, dom_bytes = kernels[dominant]
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic = None
+        traffic_from = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(dominant + "_hbm_bytes_per_launch")
+                tj = json.load(f)
+            traffic = tj.get(dominant + "_hbm_bytes_per_launch")
+            traffic_from = tj.get("collected")
         serial_ms = avg["bin"] + avg["fill"] + avg["render"] + avg["overflow"]
         out["roofline"] = {
             "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+            "traffic_from": traffic_from or "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                            "of this round; not measured in this run)",
             "algorithmic_bytes_per_launch": int(dom_bytes), "avg_kernel_ms": round(dom_ms, 5),
             "timing": "hipEvent pairs on the launch stream around each kernel (kernels launched apart and one frame at "
                       "a time for this measurement), mean of 30 frames; the bracket includes the two launch boundaries, "
-                      "about 3 us more than the dispatch duration rocprofv3 reports for the same kernel "
+                      "about 2 us more than the dispatch duration rocprofv3 reports for the same kernel "
                       "(profiles/*_one_frame_at_a_time_*)",
-            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); render_wave_kernel writes "
-                        f"the {hit_pixels} covered pixels, fill_kernel all {W * H}",
-            "note": "render_wave_kernel is VALU-issue/latency bound, not bandwidth bound (DESIGN.md section 5)",
-            "kernels_ms": {"hash_build+columns (3 kernels)": round(avg["bin"], 5),
-                           "fill_kernel": round(avg["fill"], 5),
-                           "render_wave_kernel": round(avg["render"], 5),
+            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); render_items_kernel writes "
+                        f"the {hit_pixels} covered pixels, the fill all {W * H}",
+            "note": "render_items_kernel is latency bound (a chain of dependent loads and dependent arithmetic per "
+                    "64-pixel work item), not bandwidth bound (DESIGN.md section 5); only the fill is",
+            "kernels_ms": {"hash_build+columns (bare, no fill riding)": round(avg["bin"], 5),
+                           "fill_kernel (on its own)": round(avg["fill"], 5),
+                           "render_items_kernel": round(avg["render"], 5),
                            "render_overflow_kernel": round(avg["overflow"], 5)},
             "fill_kernel": {"achieved": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9, 1),
                             "frac": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
@@ -292,25 +444,41 @@ def main():
         # every ray traced, as the reference does (PAR_RENDER_TRACE_BACKGROUND): the shadow ray of a background
         # pixel starts at (x, 0, 0) whatever its row, so it is traced once per x and its result kept per pixel
         # (scratch lit plane); same frames in flight as the headline
-        for i in range(2 * depth):
-            step(i, par.RENDER_TRACE_BACKGROUND)
-        drain()
-        k = max(5 * depth, min(1000, args.steps // 2))
+        run_block(0, 2 * depth, par.RENDER_TRACE_BACKGROUND)
+        k = max(5 * depth, min(1000, args.steps))
         t0 = time.perf_counter()
-        for i in range(k):
-            step(i, par.RENDER_TRACE_BACKGROUND)
-        drain()
+        run_block(0, k, par.RENDER_TRACE_BACKGROUND)
         dt = time.perf_counter() - t0
         out["rays"]["all_rays_traced_mrays_per_s"] = round(2.0 * W * H * k / dt / 1e6, 1)
         out["rays"]["all_rays_traced_note"] = ("every pixel's shadow ray resolved (lit mask written); the "
                                                f"{W * H - hit_pixels} background rays are {W} distinct rays "
                                                "(one per x), each traced once")
+        gpu_fb, gpu_pal = full["fb"].view(np.uint8), full["palidx"]
+        pipe.close()
+        pipe = None
+        if not args.no_extras:
+            # the dense regime (every pixel covered, every one of them a traced shadow ray) and the reference's own
+            # default scene, through the same harness: extra keys, the headline above is not touched by them
+            floor = T.make_aabbs([(i * 20, 0, j * 20, 20, 20, 20) for i in range(W // 20) for j in range(L // 20)])
+            out["dense"] = side_scene(par, pipeline, T, f"{W}x{H} full floor of {len(floor)} tiles under the same light: "
+                                      "every pixel covered, every shadow ray traced", params, floor, light, sprite,
+                                      local_rank, depth, 60)
+            p0 = T.default_params()
+            out["default_scene"] = side_scene(par, pipeline, T, "480x320x320, the reference's graybox world "
+                                              "(alt:517-599), light (480,160,80): the reference's own workload",
+                                              p0, par.scene_graybox(), T.make_light(480, 160, 80), sprite, local_rank,
+                                              depth, 2000)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(par, T, params, aabbs, light, sprite, (3 * H // 8, 5 * H // 8))
+            rows = (3 * H // 8, 5 * H // 8)
+            out["cpu_baseline"], out["verified_vs_oracle_rows"] = cpu_baseline(params, aabbs, light, sprite, rows,
+                                                                               gpu_fb, gpu_pal)
+            out["verified_vs_oracle_rows_note"] = (f"rows {rows[0]}..{rows[1]} of the GPU frame (RGBA and palette index) "
+                                                   "against the oracle band the cpu_baseline leg renders")
 
     if rank == 0:
         print(json.dumps(out))
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -119,6 +119,11 @@ int par_render_rows(par_context* ctx, int row_begin, int row_end, const par_outp
  * asynchronous frame first; par_update_aabbs_async does not. */
 int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end, const par_outputs* device_out,
                       unsigned flags);
+/* The render loop of a swap chain in one call: frames first_frame .. first_frame + n_frames - 1, frame i on slot
+ * i % n_slots (its context, its stream, its device outputs), enqueued back to back without a host wait. Each slot is
+ * a context of its own; all of them render the same rows. */
+int par_render_device_slots(par_context* const* ctxs, void* const* streams, const par_outputs* device_outs,
+                            int n_slots, int row_begin, int row_end, int first_frame, int n_frames, unsigned flags);
 /* As par_render_device, bracketing the kernel groups with HIP events on `stream`; blocks until the frame is done
  * and fills stats->ms_bin (hash build + column kernels) / ms_fill / ms_render / ms_overflow. */
 int par_render_device_timed(par_context* ctx, void* stream, int row_begin, int row_end,
@@ -161,6 +166,10 @@ int par_scene_graybox(int view_width, int view_length, par_aabb* out, int capaci
 /* Synthetic benchmark scene: n boxes of extent (20,20,20), positions from splitmix64(seed):
  * x in [-20,width), y in [-20,200), z in [-20,length). Also returns the light (5w/8, h/2, l/4). */
 int par_scene_synthetic(int n, int width, int height, int length, uint64_t seed, par_aabb* out, par_light* light);
+/* Row block [begin, end) of `rank` when one frame is sharded over `ranks` GPUs: contiguous, disjoint,
+ * covering [0, height), cut at multiples of the bin size (a bin row of 40 screen rows never straddles two ranks), the
+ * bin rows dealt as evenly as they go. */
+void par_row_block(int rank, int ranks, int height, int bin_size, int* begin, int* end);
 /* Debug overlay of alt:763-772 (Bresenham line from the picked pixel to the light) drawn into a host frame. */
 void par_debug_line(const par_params* params, const par_pixel* pick, int mouse_x, const par_light* light,
                     par_color* fb);

@@ -36,6 +36,7 @@ ABI_SYMBOLS = (
     "par_set_light", "par_render", "par_render_rows", "par_render_device", "par_render_device_timed",
     "par_graph_capture", "par_graph_stage", "par_graph_launch", "par_pick", "par_get_stats", "par_read_grid",
     "par_sprite_tile_floor", "par_scene_graybox", "par_scene_synthetic", "par_debug_line", "par_debug_units",
+    "par_render_device_slots", "par_row_block",
 )
 
 
@@ -109,6 +110,10 @@ def lib():
         L.par_scene_graybox.argtypes = [i32, i32, vp, i32]
         L.par_scene_synthetic.argtypes = [i32, i32, i32, i32, C.c_uint64, vp, vp]
         L.par_debug_units.argtypes = [i32, i32, vp, vp, i32, vp]
+        L.par_render_device_slots.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_uint]
+        L.par_row_block.restype = None
+        L.par_row_block.argtypes = [i32, i32, i32, i32, vp, vp]
+        L.par_debug_read_stamps.argtypes = [vp, vp, C.c_size_t]
         L.par_debug_line.restype = None
         L.par_debug_line.argtypes = [vp, vp, i32, vp, vp]
         _lib = L
@@ -128,6 +133,13 @@ def debug_units(kind, in_a, in_b=None, device=0):
     if rc != PAR_OK:
         raise ParError(rc, "par_debug_units")
     return out
+
+
+def row_block(rank, ranks, height, bin_size=40):
+    """Rows [begin, end) of `rank` of `ranks` GPUs sharing one frame (par_row_block): cut at bin rows."""
+    b, e = C.c_int(0), C.c_int(0)
+    lib().par_row_block(rank, ranks, height, bin_size, C.byref(b), C.byref(e))
+    return b.value, e.value
 
 
 def device_count():

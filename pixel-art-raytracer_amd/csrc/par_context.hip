@@ -1131,6 +1131,25 @@ int par_debug_units(int device, int kind, const void* in_a, const void* in_b, in
     return guarded(nullptr, [&] { return par_debug_units_impl(device, kind, in_a, in_b, n, out); });
 }
 
+static int par_render_device_slots_impl(par_context* const* ctxs, void* const* streams, const par_outputs* device_outs,
+                                        int n_slots, int row_begin, int row_end, int first_frame, int n_frames,
+                                        unsigned flags) {
+    if (!ctxs || !streams || !device_outs || n_slots < 1 || n_frames < 0 || first_frame < 0) return PAR_ERR_INVALID_ARG;
+    for (int f = first_frame; f < first_frame + n_frames; f++) {
+        const int k = f % n_slots;
+        const int rc = par_render_device(ctxs[k], streams[k], row_begin, row_end, &device_outs[k], flags);
+        if (rc != PAR_OK) return rc;
+    }
+    return PAR_OK;
+}
+int par_render_device_slots(par_context* const* ctxs, void* const* streams, const par_outputs* device_outs, int n_slots,
+                            int row_begin, int row_end, int first_frame, int n_frames, unsigned flags) {
+    return guarded(nullptr, [&] {
+        return par_render_device_slots_impl(ctxs, streams, device_outs, n_slots, row_begin, row_end, first_frame,
+                                            n_frames, flags);
+    });
+}
+
 // ---- the exported entry points of the bodies above: no exception leaves the library -----------------------
 int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) {
     return guarded(ctx, [&] { return par_set_sprites_impl(ctx, sprites, n_sprites); });

@@ -175,4 +175,16 @@ void par_debug_line(const par_params* p, const par_pixel* pick, int mouse_x, con
     }
 }
 
+// Row blocks of a frame sharded over several GPUs: cut at bin rows, the bin rows dealt evenly.
+void par_row_block(int rank, int ranks, int height, int bin_size, int* begin, int* end) {
+    if (ranks < 1) ranks = 1;
+    if (bin_size < 1) bin_size = 1;
+    rank = rank < 0 ? 0 : (rank >= ranks ? ranks - 1 : rank);
+    const long long bins = ((long long)height + bin_size - 1) / bin_size;  // bin rows, the last one maybe partial
+    const long long b0 = bins * rank / ranks, b1 = bins * (rank + 1) / ranks;
+    const long long r0 = b0 * bin_size, r1 = b1 * bin_size;
+    if (begin) *begin = (int)(r0 < height ? r0 : height);
+    if (end) *end = (int)(r1 < height ? r1 : height);
+}
+
 }  // extern "C"

@@ -8,11 +8,14 @@ pass of the reference's render call (alt:690-760) over the scene as it was when 
 
 This is host-side plumbing over the C ABI (one `par_context` per slot); a C++ host does the same with K contexts.
 """
+import ctypes as C
 import time
 
+import numpy as np
 import torch
 
-from . import Renderer, plane_bytes
+from . import Renderer, lib, plane_bytes
+from .types import Outputs
 
 
 class FrameSlot:
@@ -81,6 +84,41 @@ class FramePipeline:
 
     def slot(self, i):
         return self.slots[i % len(self.slots)]
+
+    def submit_many(self, first, n, flags=0):
+        """Enqueue frames first .. first + n - 1 round-robin over the slots with ONE call into the library
+        (par_render_device_slots): the render loop of the swap chain runs in C, not in the interpreter."""
+        if getattr(self, "_slot_args", None) is None:
+            k = len(self.slots)
+            ctxs = (C.c_void_p * k)(*[s.renderer._ctx for s in self.slots])
+            streams = (C.c_void_p * k)(*[s.stream.cuda_stream for s in self.slots])
+            outs = (Outputs * k)(*[Outputs(*[s.ptrs.get(p) for p in ("fb", "gbuf", "palidx", "brightness", "lit")])
+                                   for s in self.slots])
+            self._slot_args = (ctxs, streams, outs)
+        ctxs, streams, outs = self._slot_args
+        r0, r1 = self.slots[0].rows
+        rc = lib().par_render_device_slots(ctxs, streams, outs, len(self.slots), r0, r1, first, n, flags)
+        if rc != 0:
+            raise RuntimeError(f"par_render_device_slots failed with status {rc}")
+
+    def kernel_spans_us(self):
+        """Per kernel of the frame, the mean span (first workgroup start to last workgroup end, microseconds) over the
+        slots' most recent frames rendered with flag bit 29 (needs PAR_DEBUG_STAMPS=1 when the contexts were made)."""
+        names = ("build_fill", "resolve_fill", "columns_fill", "render_items", "render_overflow")
+        rows, wgs = 5, 8192
+        spans = {k: [] for k in names}
+        buf = np.zeros(rows * wgs * 8, dtype=np.uint64)
+        for s in self.slots:
+            rc = lib().par_debug_read_stamps(s.renderer._ctx, buf.ctypes.data_as(C.c_void_p), buf.size)
+            if rc != 0:
+                return None
+            st = buf.reshape(rows, wgs, 8)
+            for r, k in enumerate(names):
+                b, e = st[r, :, 0], st[r, :, 7]
+                live = b > 0
+                if live.any():
+                    spans[k].append((max(int(e[live].max()), int(b[live].max())) - int(b[live].min())) * 0.01)
+        return {k: round(float(np.mean(v)), 3) for k, v in spans.items() if v}
 
     def submit(self, i, flags=0):
         """Enqueue frame i on its slot's stream (asynchronous). Returns the slot."""

@@ -12,13 +12,18 @@ import torch
 import torch.distributed as dist
 
 
-def row_block(rank, world, height):
-    """Rows [begin, end) of `rank`. Blocks are contiguous, cover [0, height) exactly and differ by at most one row."""
-    return (height * rank) // world, (height * (rank + 1)) // world
+def row_block(rank, world, height, bin_size=40):
+    """Rows [begin, end) of `rank`. Blocks are contiguous, cover [0, height) exactly and are cut at multiples of the
+    bin size (a bin row never straddles two ranks, so no screen column is recorded twice); the bin rows
+    are dealt as evenly as they go (a rank may get none when there are more ranks than bin rows). The arithmetic
+    lives in the library (par_row_block) so that the C++ and Python hosts agree."""
+    from . import row_block as lib_row_block
+    return lib_row_block(rank, world, height, bin_size)
 
 
-def max_block_rows(world, height):
-    return max(row_block(r, world, height)[1] - row_block(r, world, height)[0] for r in range(world))
+def max_block_rows(world, height, bin_size=40):
+    return max(row_block(r, world, height, bin_size)[1] - row_block(r, world, height, bin_size)[0]
+               for r in range(world))
 
 
 class _Done:
@@ -32,13 +37,13 @@ class FrameGather:
     """Assembles row blocks on `dst`. With equal blocks the root receives straight into views of the final frame
     (no staging copy); otherwise blocks are padded to the largest one and unpacked on the root."""
 
-    def __init__(self, height, row_elems, dtype, device, world=None, rank=None, dst=0, group=None):
+    def __init__(self, height, row_elems, dtype, device, world=None, rank=None, dst=0, group=None, bin_size=40):
         self.group = group
         self.world = dist.get_world_size(group) if world is None else world
         self.rank = dist.get_rank(group) if rank is None else rank
         self.dst = dst
         self.height, self.row_elems = height, row_elems
-        self.blocks = [row_block(r, self.world, height) for r in range(self.world)]
+        self.blocks = [row_block(r, self.world, height, bin_size) for r in range(self.world)]
         self.max_rows = max(e - b for b, e in self.blocks)
         self.equal = all(e - b == self.max_rows for b, e in self.blocks)
         self.frame = None

@@ -456,7 +456,7 @@ def test_bench_multi_rank_control_flow(world):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
-           "--gpus", str(world), "--steps", "12", "--warmup", "3", "--backend", "gloo", "--share-gpu",
+           "--gpus", str(world), "--steps", "12", "--warmup", "3", "--blocks", "3", "--backend", "gloo", "--share-gpu",
            "--size", "1000" if world == 3 else "1024", "--no-cpu-baseline"]
     p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -464,6 +464,9 @@ def test_bench_multi_rank_control_flow(world):
     d = json.loads(line)
     assert d["n_gpus"] == world and d["steps"] == 12 and d["verified_vs_single_gpu_frame"] is True
     assert d["value"] > 0 and d["scaling"] == "strong"
+    mg = d["multi_gpu"]
+    assert len(mg["ranks_seen"]) == world and mg["render_ms"] > 0 and mg["gather_ms"] > 0
+    assert mg["gather_bytes_per_rank"] > 0 and d["ms_per_step_spread"]["blocks"] == 3
 
 
 def test_host_demo_gif(par, oracle, T, tmp_path):
