@@ -713,6 +713,24 @@ def test_cpp_pipeline_host(par):
         assert line["host"] == "C++" and line["frames_per_s"] > 0
 
 
+def test_cpp_ranks_host_gathers_over_rccl(par, tmp_path):
+    """The sharded-frame loop in host C++ (par_ranks): one process per GPU, row blocks cut at bin rows, ONE ncclGather
+    per frame enqueued behind the render on the frame's stream. A one-GPU box can run it with one rank (RCCL's gather
+    of the only block), which still executes the whole per-frame path: communicator set-up from the id file, render
+    into the block, gather, assembled frame equal to the whole-frame render (--check)."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(par.LIB_PATH), "par_ranks")
+    assert os.path.exists(exe), "build with make -C pixel-art-raytracer_amd/csrc"
+    p = subprocess.run([exe, "--ranks", "1", "--rank", "0", "--id-file", str(tmp_path / "rccl_ids"), "--size", "1024",
+                        "--prims", "300", "--frames", "80", "--inflight", "3", "--check"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "check: ok" in p.stdout, p.stdout + p.stderr
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["host"] == "C++ ranks" and line["ranks"] == 1 and line["gather_bytes_per_rank"] == 1024 * 1024 * 4
+
+
 def test_one_launch_hash_build_equals_two_launches(par, oracle, sprite, T):
     """Small scenes build the spatial hash in ONE launch (insert, a barrier among the build workgroups, resolve)
     instead of two, and the work items of columns that hold one entity and cast no shadow on themselves carry all the
