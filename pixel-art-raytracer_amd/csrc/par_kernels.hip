@@ -982,13 +982,17 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
             cur_bz = bz;
             hit_in_bin = false;
         };
+        const bool has_ids = a.sprite_ids != nullptr;
         auto test = [&](const par_slot& rec, int e) {
             const int top = rec.py + rec.ey + rec.pz + rec.ez;
-            if (!done && i >= rec.px && i < rec.px + rec.ex && world_j > rec.py + rec.pz && world_j <= top) {
+            // alt:310-317 (one predicate: no branch per condition)
+            const bool inside = (!done) & (i >= rec.px) & (i < rec.px + rec.ex) & (world_j > rec.py + rec.pz) &
+                                (world_j <= top);
+            if (inside) {
                 first_cover = min(first_cover, e);
                 const int sprite_row = top - world_j;                         // alt:324-326
                 const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
-                const int sid = a.sprite_ids ? a.sprite_ids[rec.entity] : 0;  // alt:321-322
+                const int sid = has_ids ? a.sprite_ids[rec.entity] : 0;       // alt:321-322
                 const int d = (sid == 0) ? depth0[t] : a.sprites[sid].depth[t];
                 const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
                 if (closest < depth) {                                        // alt:344-346
@@ -1003,21 +1007,42 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
                 }
             }
         };
-        if (!GENERIC) {  // the record's entries as one flat list
-            for (int e = 0; e < n_entries; e++) {
+        if (!GENERIC) {
+            // The record's entries as one flat list, front to back. Lane e holds entry e: ONE vector comparison says
+            // which entries can cover a pixel of this chunk at all (not a repeat of an earlier entry's entity: the
+            // same AABB in another bin gives the same depth, so it can neither improve `closest`, strict compare
+            // alt:344, nor be the first to cover; and its rows meet the chunk's rows [row_lo, row_hi]); only those
+            // are visited. The bins of the entries skipped are occupied bins without a hit: they leave `adjacent`
+            // alone (only an EMPTY bin resets it, alt:298-300), so all the visit needs to know of them is whether
+            // an empty bin lies between two visited ones: `gaps` counts the empty stretches up to an entry's bin.
+            const int16_t my_px = (int16_t)(cr.ent.x & 0xFFFF), my_py = (int16_t)(cr.ent.x >> 16);
+            const int16_t my_pz = (int16_t)(cr.ent.y & 0xFFFF);
+            const int16_t my_ey = (int16_t)(cr.ent.z & 0xFFFF), my_ez = (int16_t)(cr.ent.z >> 16);
+            (void)my_px;
+            const int my_top_row = H - (my_py + my_ey + my_pz + my_ez), my_end_row = H - (my_py + my_pz);
+            const bool mine = lane < n_entries && !((dup >> lane) & 1) && !(row_hi < my_top_row || row_lo >= my_end_row);
+            uint64_t todo = __ballot(mine);
+            const int prev_bz = __shfl_up(cr.ebz, 1);
+            const uint64_t gap_mask = __ballot(lane > 0 && lane < n_entries && cr.ebz != prev_bz && cr.ebz != prev_bz + 1);
+            const int my_gaps = __popcll(gap_mask & ((2ull << lane) - 1ull));
+            int cur_gaps = -1;
+            while (todo) {
+                const int e = __builtin_ctzll(todo);
+                todo &= todo - 1;
                 const int bz = __builtin_amdgcn_readlane(cr.ebz, e);
-                if (bz != cur_bz) next_bin(bz);
-                // An entry that repeats an earlier entry's entity (the same AABB in another bin) gives the same
-                // depth: it can neither improve `closest` (strict compare, alt:344) nor be the first to cover.
-                if ((dup >> e) & 1) continue;
-                const par_slot rec = slot_of_lane(cr.ent, e);
-                // (wave-uniform) an entry whose rows miss the chunk's rows [row_lo, row_hi] covers none of its
-                // pixels: dense columns list many entries, a chunk meets few of them
-                if (row_hi < H - (rec.py + rec.ey + rec.pz + rec.ez) || row_lo >= H - (rec.py + rec.pz)) continue;
+                if (bz != cur_bz) {  // the previous visited bin is complete (next_bin, across the bins skipped)
+                    const int gaps = __builtin_amdgcn_readlane(my_gaps, e);
+                    adjacent += hit_in_bin ? 1 : 0;         // alt:368
+                    if (adjacent >= 2) done = true;         // alt:372-374
+                    if (gaps != cur_gaps) adjacent = 0;     // an empty bin lies in between (alt:298-300)
+                    cur_gaps = gaps;
+                    cur_bz = bz;
+                    hit_in_bin = false;
+                }
                 // a lane whose pixel an earlier entry owns has nothing to do in this pass
                 if (first_cover < own) done = true;  // (never in tile mode: own = -1)
                 if (__all(done)) break;  // wavefront early-out
-                test(rec, e);
+                test(slot_of_lane(cr.ent, e), e);
             }
         } else {  // the column's bins as they lie in the hash, alt:292-376
             const int col_base = flat_index(g.gy, g.gz, bx, by, 0);

@@ -10,6 +10,8 @@ T = par.types
 W = H = L = 4096
 p = T.default_params(W, H, L)
 a, l = par.scene_synthetic(1024, W, H, L, 12345)
+if len(sys.argv) > 1 and sys.argv[1] == "floor":
+    a = T.make_aabbs([(i * 20, 0, j * 20, 20, 20, 20) for i in range(W // 20) for j in range(L // 20)])
 r = par.Renderer(p, 0)
 r.set_scene(a, par.tile_floor(), l)
 fb = torch.zeros(W * H * 4, dtype=torch.uint8, device="cuda"); pal = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
