@@ -80,6 +80,9 @@ struct par_frame_dyn {
     int32_t lbx, lby, lbz;  // its bin (alt:729-732)
 };
 
+// Render flags that make the render launch use its instrumented variant (ray counting, the timing-experiment bits
+// 24-26 and the time stamps, bit 29); a production frame has none of them and runs kernels compiled without them.
+constexpr uint32_t PAR_DEBUG_FLAGS = PAR_RENDER_COUNT_RAYS | (7u << 24) | (1u << 29);
 constexpr int PAR_WAVE_NW = 4;          // wavefronts per render workgroup
 // Render work items: columns_kernel lists every 64-pixel chunk of every column with a record as one item (par_item);
 // pass = the entry whose rectangle is visited, PAR_ITEM_TILE = the whole tile. An item of a SIMPLE column (all its

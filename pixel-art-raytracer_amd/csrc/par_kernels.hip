@@ -941,12 +941,15 @@ __device__ __forceinline__ par_slot slot_of_lane(const uint4& v, int e) {
     return r;
 }
 
-template <bool GENERIC>
+// DBG: the debug / instrumentation flags of the frame are looked at (ablation bits 24-26, time stamps bit 29, ray
+// counting); the production kernels are compiled without them.
+template <bool GENERIC, bool DBG>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
                                              const ColumnRegs& cr, uint64_t dup, const par_frame_dyn& dyn,
                                              int n_entries, int n_nb, int bx, int by, int own, int col, int row,
                                              int row_lo, int row_hi, bool valid, int lane, WaveScratch* ws) {
     const int W = a.W, H = a.H;
+    const uint32_t fl = DBG ? a.flags : 0u;
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
     const int32_t* depth0 = a.sprites[0].depth;
@@ -1063,14 +1066,14 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         }
     }
 
-    if (!GENERIC) stamp(g, a.flags, 3, 3);
+    if (!GENERIC) stamp(g, fl, 3, 3);
     // ---- shading, alt:704-758 ---------------------------------------------------------------------------------
     float nx = 0.f, ny = 0.f, nz = 0.f;
     uint32_t rgba = bg_rgba;
     int pal_index = PAR_PALIDX_BACKGROUND;
     float bright = ambient;
     bool lit = true;
-    const bool shade = hit && !(a.flags & (1u << 26));  // bit 26: ablation (timing experiments only), no shading
+    const bool shade = hit && !(fl & (1u << 26));  // bit 26: ablation (timing experiments only), no shading
     bool need_walk = false;  // the shadow ray still has to be resolved
     float inv_x = 0.f, inv_y = 0.f, inv_z = 0.f, b_lit = 0.f;
     int sy = 0, sz = 0, ox = 0, oy = 0, oz = 0;
@@ -1165,14 +1168,14 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
     }
     if (shade) bright = lit ? b_lit : ambient;
     const bool lit_px = lit;
-    if (!GENERIC) stamp(g, a.flags, 3, 4);
-    if ((a.flags & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
+    if (!GENERIC) stamp(g, fl, 3, 4);
+    if ((fl & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
         const unsigned long long m = __ballot(valid && hit);
         if (lane == 0 && m) atomicAdd(a.ray_counter, (unsigned long long)__popcll(m));
     }
 
     // ---- quantise + store, alt:735, 757-758 -------------------------------------------------------------------
-    if (a.flags & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
+    if (fl & (1u << 25)) {  // bit 25: ablation (timing only), no stores; keep the values alive
         asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
     } else if (valid && hit) {  // (uncovered pixels keep what the fill wrote)
         const size_t o = (size_t)(row - a.row_begin) * W + col;
@@ -1231,7 +1234,7 @@ __device__ __forceinline__ void render_column_generic(const par_grid_dev& g, con
         const int p_first = c * 64, p_last = min(p_first + 63, area - 1);
         const int row_lo = ry0 + ((rw == 1) ? p_first : (int)__umulhi((uint32_t)p_first, magic_w));
         const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
-        render_chunk<true>(g, a, rec_, cr, 0, dyn, 0, 0, bx, by, -1, col, row, row_lo, row_hi, pidx < area, lane,
+        render_chunk<true, true>(g, a, rec_, cr, 0, dyn, 0, 0, bx, by, -1, col, row, row_lo, row_hi, pidx < area, lane,
                            ws + wave);
     }
 }
@@ -1243,8 +1246,10 @@ __device__ __forceinline__ void render_column_generic(const par_grid_dev& g, con
 // (v_readlane). No LDS, no barrier, no loop over chunks: every wavefront of the launch is a handful of dependent
 // loads long, whatever its column looks like.
 // The item as two 16-byte words (par_item: {ci, visit, where, bins}, {entry}).
+template <bool DBG>
 __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, uint4 ib,
                                             int lane) {
+    const uint32_t fl = DBG ? a.flags : 0u;
     const int ci = (int)ia.x;
     const uint32_t pass = ia.y >> 16;
     const int chunk = (int)(ia.y & 0xFFFFu);
@@ -1269,14 +1274,17 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
         cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
         cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
         cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
-        n_entries_rec = rec_.n_entries;
-        n_nb = rec_.n_nb;
-        bx = rec_.bx;
-        by = rec_.by;
-        dup = ((uint64_t)rec_.dup_hi << 32) | rec_.dup_lo;
-        if (rec_.overflow) return;  // render_overflow_kernel's
+        // the record's header (32 bytes, wave-uniform, written by the column launch): two scalar loads
+        const uint4 h0 = ld_uniform(reinterpret_cast<const uint4*>(&rec_));
+        const uint4 h1 = ld_uniform(reinterpret_cast<const uint4*>(&rec_) + 1);
+        n_nb = (int)(int16_t)(h0.x & 0xFFFFu);
+        n_entries_rec = (int)(int16_t)(h0.x >> 16);
+        bx = (int)(int16_t)(h0.z & 0xFFFFu);
+        by = (int)(int16_t)(h0.z >> 16);
+        dup = ((uint64_t)h1.z << 32) | h1.y;
+        if ((h0.y >> 16) != 0) return;  // overflow: render_overflow_kernel's
     }
-    stamp(g, a.flags, 3, 2);
+    stamp(g, fl, 3, 2);
     // The shadow test will read the walk list of the pixel's start bin, which is known only after the primary pass
     // and its depth lookups: lane n touches the first line of bin n's list now, so that those reads find it in the
     // cache instead of adding a round trip to memory at the end of the chain.
@@ -1284,9 +1292,9 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     if (!simple && lane < n_nb && (int)(int16_t)(cr.nb.y >> 16) > 0) {
         touched = *reinterpret_cast<const uint32_t*>(rec_.walk + (cr.nb.y & 0xFFFFu));
     }
-    const int n_entries = (a.flags & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
+    const int n_entries = (fl & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
     const int W = a.W, H = a.H, B = a.B;
-    const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
+    const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
     const int c0 = bx * B;
     const int tw = min(B, W - c0);
     const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
@@ -1312,21 +1320,25 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const int area = rw * rh;
     const int p_first = chunk * 64, p_last = min(p_first + 63, area - 1);
     if (p_first >= area) return;
-    // floor(p / rw) == __umulhi(p, magic_w) for p * rw < 2^32; a 1-pixel-wide rectangle has no such multiplier
-    const uint32_t magic_w = (uint32_t)(0xFFFFFFFFu / (uint32_t)rw) + 1u;
+    // floor(p / rw) through a float reciprocal: p < 2^15 and rw <= PAR_MAX_BIN, so (p + 0.5) / rw is at least
+    // 0.5 / PAR_MAX_BIN away from every integer, far more than the rounding of the three float operations
+    // (an integer division by a run-time value costs some forty instructions per wavefront)
+    const float inv_rw = __builtin_amdgcn_rcpf((float)rw);
+    auto div_rw = [&](int p) { return (int)(((float)p + 0.5f) * inv_rw); };
     const int pidx = p_first + lane;
-    const int pyy = (rw == 1) ? pidx : (int)__umulhi((uint32_t)pidx, magic_w);
+    const int pyy = div_rw(pidx);
     const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
     // the chunk's first and last row (wave-uniform)
-    const int row_lo = ry0 + ((rw == 1) ? p_first : (int)__umulhi((uint32_t)p_first, magic_w));
-    const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
-    render_chunk<false>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, pidx < area,
-                        lane, nullptr);
+    const int row_lo = ry0 + __builtin_amdgcn_readfirstlane(div_rw(p_first));
+    const int row_hi = ry0 + __builtin_amdgcn_readfirstlane(div_rw(p_last));
+    render_chunk<false, DBG>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi,
+                             pidx < area, lane, nullptr);
     asm volatile("" ::"v"(touched));  // (keeps the touch alive; nothing reads it)
 }
 
 // Wavefront `w` of `n_waves` (a multiple of PAR_ITEM_SHARDS): items w / shards, + n_waves / shards, ... of shard
 // w mod shards. The launch offers one wavefront per item of the host's bound, so the loop normally runs once.
+template <bool DBG>
 __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
     const int lane = (int)threadIdx.x & 63;
     const int shard = w & (PAR_ITEM_SHARDS - 1);
@@ -1336,10 +1348,10 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     u32x8 it = item_fetch(list + min(first, g.item_capacity - 1));
     const int n = min(ld_uniform(g.item_counters + shard * PAR_ITEM_COUNTER_STRIDE), g.item_capacity);
     item_arrived(it);
-    stamp(g, a.flags, 3, 1);
+    stamp(g, DBG ? a.flags : 0u, 3, 1);
     for (int i = first; i < n;) {
         if (it[0] != PAR_ITEM_NONE) {
-            render_item(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
+            render_item<DBG>(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
         }
         i += n_waves >> PAR_ITEM_SHARD_BITS;
         if (i < n) {
@@ -1349,11 +1361,12 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     }
 }
 
+template <bool DBG>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid_dev g, par_render_args a) {
-    stamp(g, a.flags, 3, 0);
+    stamp(g, DBG ? a.flags : 0u, 3, 0);
     const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-    render_items(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
-    stamp(g, a.flags, 3, 7);
+    render_items<DBG>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
+    stamp(g, DBG ? a.flags : 0u, 3, 7);
 }
 
 // The columns that overflowed their record (columns_kernel lists them), or every column when a.dense
@@ -1380,13 +1393,14 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_overflow_kernel(par_g
 // Both of the above in one launch, for small frames: there a frame is bound by its launches (the host enqueues one
 // in about 3 us, the device needs about 1.5 us between two), not by the registers the overflow path costs the others.
 // Workgroups [0, n_item_wgs) render the work items, the rest (groups of `over_parts`) the overflow list.
+template <bool DBG>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_dev g, par_render_args a,
                                                                           int n_item_wgs, int over_parts) {
     __shared__ WaveScratch scratch[PAR_WAVE_NW];
     const int b = (int)blockIdx.x;
     if (b < n_item_wgs) {
         const int w = __builtin_amdgcn_readfirstlane(b * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-        render_items(g, a, w, n_item_wgs * PAR_WAVE_NW);
+        render_items<DBG>(g, a, w, n_item_wgs * PAR_WAVE_NW);
         return;
     }
     const int j = b - n_item_wgs;  // (workgroups of this kind exist only when some column may overflow)
@@ -1615,8 +1629,13 @@ static int64_t item_workgroups(int64_t item_bound) {
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
                              hipStream_t stream) {
     if (item_bound <= 0 || a.dense) return hipSuccess;
-    hipLaunchKernelGGL(render_items_kernel, dim3((unsigned)item_workgroups(item_bound)), dim3(PAR_WAVE_NW * 64), 0,
-                       stream, g, a);
+    if (a.flags & PAR_DEBUG_FLAGS) {
+        hipLaunchKernelGGL(render_items_kernel<true>, dim3((unsigned)item_workgroups(item_bound)), dim3(PAR_WAVE_NW * 64),
+                           0, stream, g, a);
+    } else {
+        hipLaunchKernelGGL(render_items_kernel<false>, dim3((unsigned)item_workgroups(item_bound)),
+                           dim3(PAR_WAVE_NW * 64), 0, stream, g, a);
+    }
     return hipGetLastError();
 }
 
@@ -1631,8 +1650,13 @@ hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& 
     const int over_parts = 8;
     const int64_t over_cols = !may_overflow ? 0 : (bound < 32 ? bound : 32);
     const int64_t n_item_wgs = item_workgroups(item_bound);
-    hipLaunchKernelGGL(render_both_kernel, dim3((unsigned)(n_item_wgs + over_cols * over_parts)),
-                       dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs, over_parts);
+    if (a.flags & PAR_DEBUG_FLAGS) {
+        hipLaunchKernelGGL(render_both_kernel<true>, dim3((unsigned)(n_item_wgs + over_cols * over_parts)),
+                           dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs, over_parts);
+    } else {
+        hipLaunchKernelGGL(render_both_kernel<false>, dim3((unsigned)(n_item_wgs + over_cols * over_parts)),
+                           dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs, over_parts);
+    }
     return hipGetLastError();
 }
 
