@@ -25,6 +25,8 @@
 
 #include <limits.h>
 
+#include <cstdlib>
+
 namespace {
 
 // Debug time stamps (PAR_DEBUG_STAMPS=1): lane 0 of a workgroup notes the 100 MHz wall clock at phase boundaries
@@ -1460,8 +1462,15 @@ bool par_plan_fill(const par_render_args& a, par_fill_plan* plan) {
     plan->cut[0] = 0;
     // (Measured at 4096^2, three frames in flight: 0/0/100 % 36.5 us per frame, 10/10/80 35.7, 20/20/60 34.1,
     // 25/25/50 34.5, 33/33/33 34.0.)
-    plan->cut[1] = (int)(chunks / 5);
-    plan->cut[2] = (int)(chunks * 2 / 5);
+    // (PAR_TUNE_FILL_BUILD_PCT: the hash build's share in percent, tools/sweep.py; default 40, half of it per launch
+    // when the build takes two)
+    static const int build_pct = [] {
+        const char* e = std::getenv("PAR_TUNE_FILL_BUILD_PCT");
+        const int v = e ? std::atoi(e) : 40;
+        return v < 0 ? 0 : (v > 100 ? 100 : v);
+    }();
+    plan->cut[1] = (int)(chunks * build_pct / 200);
+    plan->cut[2] = (int)(chunks * build_pct / 100);
     plan->cut[3] = (int)chunks;
     return true;
 }
@@ -1471,7 +1480,12 @@ bool par_plan_fill(const par_render_args& a, par_fill_plan* plan) {
 // kernels cannot use. Measured at 4096^2 (three frames in flight / one), workgroups in the insert and resolve
 // launches / in the column launch: 256 / 1024: 34.6 / 59.5 us, 128 / 512: 32.7 / 58.3, 64 / 256: 31.5 / 58.1,
 // 32 / 128: 33.1 / 66.8, 16 / 64: 40.7 / 94.7.
-constexpr int PAR_FILL_RIDE_WGS = 64;
+// (PAR_TUNE_FILL_WGS overrides the 64, tools/sweep.py)
+static const int PAR_FILL_RIDE_WGS = [] {
+    const char* e = std::getenv("PAR_TUNE_FILL_WGS");
+    const int v = e ? std::atoi(e) : 64;
+    return v < 1 ? 1 : (v > 4096 ? 4096 : v);
+}();
 static int64_t fill_blocks(const par_fill_plan& p, int i, int waves, int64_t cap) {
     const int64_t chunks = p.cut[i + 1] - p.cut[i];
     int64_t n = (chunks + waves - 1) / waves;

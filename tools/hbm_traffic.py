@@ -6,6 +6,7 @@ bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section).
 import collections, csv, glob, json, os, statistics, sys
 
 root = sys.argv[1]
+collected = sys.argv[2] if len(sys.argv) > 2 else "unknown commit"
 raw = collections.defaultdict(dict)
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(root, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True)
@@ -23,7 +24,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             per[name].append(float(r["Counter_Value"]))
     for name, v in per.items():
         raw[name][counter] = statistics.median(v)
-out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 "
+out = {"collected": collected,
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 "
                  "tools/frames.py synthetic 40 (4096x4096, 1024 primitives); median over dispatches; MI355X",
        "units": "counter values are KiB; hbm bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE counts half "
                 "of wide 16-B/lane reads, MI355X_MICROARCH.md HBM section)",
