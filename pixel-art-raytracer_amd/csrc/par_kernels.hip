@@ -651,6 +651,7 @@ __device__ __forceinline__ void columns_block(const par_grid_dev& g, const par_r
                                               int32_t* others_found, int block, int n_cols_bound) {
     static_assert(PAR_COL_WAVES == PAR_COL_ROLES, "a column's wavefronts are its whole workgroup (columns_wave's barrier)");
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
     columns_wave(g, a, sm[wave], others_found, block, wave, n_cols_bound);
 }
 
@@ -943,30 +944,27 @@ __device__ __forceinline__ par_slot slot_of_lane(const uint4& v, int e) {
     return r;
 }
 
+// What an entry pass fetched ahead of its own entry's texel (tex = -1: nothing).
+struct OwnTexel {
+    int tex, pal, depth;
+    par_texel ti;
+};
+
 // DBG: the debug / instrumentation flags of the frame are looked at (ablation bits 24-26, time stamps bit 29, ray
 // counting); the production kernels are compiled without them.
 template <bool GENERIC, bool DBG>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
                                              const ColumnRegs& cr, uint64_t dup, const par_frame_dyn& dyn,
                                              int n_entries, int n_nb, int bx, int by, int own, int col, int row,
-                                             int row_lo, int row_hi, bool valid, int lane, WaveScratch* ws) {
+                                             int row_lo, int row_hi, bool valid, int lane, WaveScratch* ws,
+                                             const OwnTexel& pre = OwnTexel{-1, 0, 0, par_texel{0.f, 0.f, 0.f, 0u}}) {
     const int W = a.W, H = a.H;
     const uint32_t fl = DBG ? a.flags : 0u;
     const float ambient = a.ambient;
     const uint32_t bg_rgba = a.background | (a.background << 8) | (a.background << 16);
     const int32_t* depth0 = a.sprites[0].depth;
-    // An entry pass visits the rectangle of entry `own`: its texel is the likeliest winner of the lane's pixel, so
-    // what the shading needs of it (normal, colour, palette index) is fetched now, beside the primary pass's depth
-    // lookups, instead of a dependent round trip after them. (With a sprite-id table the texel is not known yet.)
-    int pre_tex = -1, pre_pal = 0;
-    par_texel pre_ti = par_texel{0.f, 0.f, 0.f, 0u};
-    if (!GENERIC && own >= 0 && valid && !a.sprite_ids) {
-        const par_slot r = slot_of_lane(cr.ent, own);
-        const int sprite_row = r.py + r.ey + r.pz + r.ez - (int)(int16_t)(H - row);  // alt:324-326
-        pre_tex = sprite_row * PAR_SPRITE_W + (col - r.px);                           // alt:330-332
-        pre_ti = a.texinfo[pre_tex];
-        if (a.out.palidx) pre_pal = a.sprites[0].color[pre_tex];
-    }
+    const int pre_tex = pre.tex, pre_pal = pre.pal;
+    const par_texel pre_ti = pre.ti;
     // ---- primary ray, alt:271-397: the column's slot records front to back ------------------------------------
     bool hit = false;
     int p_entity = 0, p_y = 0, p_z = 0, p_tex = 0;
@@ -998,7 +996,9 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
                 const int sprite_row = top - world_j;                         // alt:324-326
                 const int t = sprite_row * PAR_SPRITE_W + (i - rec.px);       // alt:330-332
                 const int sid = has_ids ? a.sprite_ids[rec.entity] : 0;       // alt:321-322
-                const int d = (sid == 0) ? depth0[t] : a.sprites[sid].depth[t];
+                // (an entry pass has its own entry's texel already: same index, same table)
+                const int d = (!GENERIC && t == pre_tex && e == own) ? pre.depth
+                                                                       : ((sid == 0) ? depth0[t] : a.sprites[sid].depth[t]);
                 const int depth = rec.py - rec.pz + min(0, rec.ey - sprite_row) - d;  // alt:336-341
                 if (closest < depth) {                                        // alt:344-346
                     closest = depth;
@@ -1256,68 +1256,31 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const uint32_t pass = ia.y >> 16;
     const int chunk = (int)(ia.y & 0xFFFFu);
     const bool simple = (ia.z & PAR_ITEM_SIMPLE) != 0;
+    const bool tile_mode = pass == PAR_ITEM_TILE;
     const par_colrec& rec_ = g.colrec[ci];
-    ColumnRegs cr;
-    int n_entries_rec, n_nb, bx, by;
-    uint64_t dup;
-    if (simple) {
-        // all the column has to say is in the item: one entry (every lane holds it; it is entry 0 of the list and
-        // the pass), the occupied bins bins.first .. bins.last, each with an empty walk
-        const int bz_first = (int)(ia.w & 0xFFFFu), bz_last = (int)(ia.w >> 16);
-        cr.ent = ib;  // (par_slot as it lies in memory)
-        cr.ebz = bz_first;
-        cr.nb = make_uint2((uint32_t)(uint16_t)(bz_first + lane), 0u);  // lane n: bin first + n, walk [0, 0)
-        n_entries_rec = 1;
-        n_nb = bz_last - bz_first + 1;
-        bx = (int)(ia.z & 0x3FFu);
-        by = (int)((ia.z >> 10) & 0x3FFu);
-        dup = 0;
-    } else {
-        cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
-        cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
-        cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
-        // the record's header (32 bytes, wave-uniform, written by the column launch): two scalar loads
-        const uint4 h0 = ld_uniform(reinterpret_cast<const uint4*>(&rec_));
-        const uint4 h1 = ld_uniform(reinterpret_cast<const uint4*>(&rec_) + 1);
-        n_nb = (int)(int16_t)(h0.x & 0xFFFFu);
-        n_entries_rec = (int)(int16_t)(h0.x >> 16);
-        bx = (int)(int16_t)(h0.z & 0xFFFFu);
-        by = (int)(int16_t)(h0.z >> 16);
-        dup = ((uint64_t)h1.z << 32) | h1.y;
-        if ((h0.y >> 16) != 0) return;  // overflow: render_overflow_kernel's
-    }
-    stamp(g, fl, 3, 2);
-    // The shadow test will read the walk list of the pixel's start bin, which is known only after the primary pass
-    // and its depth lookups: lane n touches the first line of bin n's list now, so that those reads find it in the
-    // cache instead of adding a round trip to memory at the end of the chain.
-    uint32_t touched = 0;
-    if (!simple && lane < n_nb && (int)(int16_t)(cr.nb.y >> 16) > 0) {
-        touched = *reinterpret_cast<const uint32_t*>(rec_.walk + (cr.nb.y & 0xFFFFu));
-    }
-    const int n_entries = (fl & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
+    // ---- everything the ITEM says: the column, the rectangle visited, this lane's pixel, and (entry passes) the
+    // texel of the pass's own entry, the likeliest winner of the pixel. Its depth, normal, colour and palette index
+    // are fetched right away, beside the column's record, instead of one and two round trips after it.
     const int W = a.W, H = a.H, B = a.B;
-    const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
+    const int bx = (int)(ia.z & 0x3FFu), by = (int)((ia.z >> 10) & 0x3FFu);
     const int c0 = bx * B;
     const int tw = min(B, W - c0);
     const int rows_lo = max(by * B, a.row_begin), rows_hi = min(min((by + 1) * B, H), a.row_end);
-    const bool tile_mode = pass == PAR_ITEM_TILE;
-    // (a simple column's only entry sits in every lane: it is read as entry 0 whatever its index in the record was)
-    const int own = tile_mode ? -1 : (simple ? 0 : (int)pass);
+    par_slot own_rec;  // the pass's entry as the item carries it (par_slot as it lies in memory)
+    own_rec.px = (int16_t)(ib.x & 0xFFFFu); own_rec.py = (int16_t)(ib.x >> 16);
+    own_rec.pz = (int16_t)(ib.y & 0xFFFFu); own_rec.ex = (int16_t)(ib.y >> 16);
+    own_rec.ey = (int16_t)(ib.z & 0xFFFFu); own_rec.ez = (int16_t)(ib.z >> 16);
+    own_rec.entity = (int32_t)ib.w;
     int rx0, rw, ry0, rh;
     if (tile_mode) {
         rx0 = c0; rw = tw; ry0 = rows_lo; rh = rows_hi - rows_lo;
     } else {
-        const par_slot r = slot_of_lane(cr.ent, own);
-        rx0 = max((int)r.px, c0);
-        rw = min(r.px + r.ex, c0 + tw) - rx0;
+        rx0 = max((int)own_rec.px, c0);
+        rw = min(own_rec.px + own_rec.ex, c0 + tw) - rx0;
         // alt:314-317: world_j in (py+pz, py+ey+pz+ez], and row = H - world_j (alt:280)
-        ry0 = max(H - (r.py + r.ey + r.pz + r.ez), rows_lo);
-        rh = min(H - (r.py + r.pz), rows_hi) - ry0;
+        ry0 = max(H - (own_rec.py + own_rec.ey + own_rec.pz + own_rec.ez), rows_lo);
+        rh = min(H - (own_rec.py + own_rec.pz), rows_hi) - ry0;
     }
-    rx0 = __builtin_amdgcn_readfirstlane(rx0);
-    rw = __builtin_amdgcn_readfirstlane(rw);
-    ry0 = __builtin_amdgcn_readfirstlane(ry0);
-    rh = __builtin_amdgcn_readfirstlane(rh);
     if (rw <= 0 || rh <= 0) return;
     const int area = rw * rh;
     const int p_first = chunk * 64, p_last = min(p_first + 63, area - 1);
@@ -1330,11 +1293,60 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const int pidx = p_first + lane;
     const int pyy = div_rw(pidx);
     const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
+    const bool valid = pidx < area;
     // the chunk's first and last row (wave-uniform)
     const int row_lo = ry0 + __builtin_amdgcn_readfirstlane(div_rw(p_first));
     const int row_hi = ry0 + __builtin_amdgcn_readfirstlane(div_rw(p_last));
-    render_chunk<false, DBG>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi,
-                             pidx < area, lane, nullptr);
+    OwnTexel pre;
+    pre.tex = -1; pre.pal = 0; pre.depth = 0;
+    pre.ti = par_texel{0.f, 0.f, 0.f, 0u};
+    if (!tile_mode && valid && !a.sprite_ids) {  // (with a sprite-id table the texel is not known yet)
+        const int sprite_row = own_rec.py + own_rec.ey + own_rec.pz + own_rec.ez - (int)(int16_t)(H - row);  // alt:324-326
+        pre.tex = sprite_row * PAR_SPRITE_W + (col - own_rec.px);                                            // alt:330-332
+        pre.depth = a.sprites[0].depth[pre.tex];
+        pre.ti = a.texinfo[pre.tex];
+        if (a.out.palidx) pre.pal = a.sprites[0].color[pre.tex];
+    }
+    // ---- what the column's RECORD says (not needed for a simple column: its item says it all) ------------------
+    ColumnRegs cr;
+    int n_entries_rec, n_nb;
+    uint64_t dup;
+    if (simple) {
+        // one entry (every lane holds it; it is entry 0 of the list and the pass), the occupied bins bins.first ..
+        // bins.last, each with an empty walk
+        const int bz_first = (int)(ia.w & 0xFFFFu), bz_last = (int)(ia.w >> 16);
+        cr.ent = ib;
+        cr.ebz = bz_first;
+        cr.nb = make_uint2((uint32_t)(uint16_t)(bz_first + lane), 0u);  // lane n: bin first + n, walk [0, 0)
+        n_entries_rec = 1;
+        n_nb = bz_last - bz_first + 1;
+        dup = 0;
+    } else {
+        cr.ent = reinterpret_cast<const uint4*>(rec_.entries)[min(lane, PAR_COL_ENT - 1)];
+        cr.ebz = rec_.ebz[min(lane, PAR_COL_ENT - 1)];
+        cr.nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];
+        // the record's header (32 bytes, wave-uniform, written by the column launch): two scalar loads
+        const uint4 h0 = ld_uniform(reinterpret_cast<const uint4*>(&rec_));
+        const uint4 h1 = ld_uniform(reinterpret_cast<const uint4*>(&rec_) + 1);
+        n_nb = (int)(int16_t)(h0.x & 0xFFFFu);
+        n_entries_rec = (int)(int16_t)(h0.x >> 16);
+        dup = ((uint64_t)h1.z << 32) | h1.y;
+        if ((h0.y >> 16) != 0) return;  // overflow: render_overflow_kernel's
+    }
+    stamp(g, fl, 3, 2);
+    // The shadow test will read the walk list of the pixel's start bin, which is known only after the primary pass
+    // and its depth lookups: lane n touches the first line of bin n's list now, so that those reads find it in the
+    // cache instead of adding a round trip to memory at the end of the chain.
+    uint32_t touched = 0;
+    if (!simple && lane < n_nb && (int)(int16_t)(cr.nb.y >> 16) > 0) {
+        touched = *reinterpret_cast<const uint32_t*>(rec_.walk + (cr.nb.y & 0xFFFFu));
+    }
+    const int n_entries = (fl & (1u << 24)) ? 0 : n_entries_rec;  // bit 24: ablation (timing only)
+    const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
+    // (a simple column's only entry sits in every lane: it is read as entry 0 whatever its index in the record was)
+    const int own = tile_mode ? -1 : (simple ? 0 : (int)pass);
+    render_chunk<false, DBG>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, valid,
+                             lane, nullptr, pre);
     asm volatile("" ::"v"(touched));  // (keeps the touch alive; nothing reads it)
 }
 
@@ -1366,6 +1378,7 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
 template <bool DBG>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid_dev g, par_render_args a) {
     stamp(g, DBG ? a.flags : 0u, 3, 0);
+    __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
     const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
     render_items<DBG>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
     stamp(g, DBG ? a.flags : 0u, 3, 7);
