@@ -346,15 +346,17 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
     for (int it0 = 0; it0 < m; it0 += 64) {
         const int n_it = min(64, m - it0);
         if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
-            // Always 64 steps, unrolled (a loop with a data-dependent trip count costs a taken branch per step, 2 us
-            // per walk): entries past n_it are never read, and a round shorter than 64 is the walk's last, so the
-            // carry is not needed after it either.
+            // Blocks of 16 unrolled steps (a loop with a branch per step costs 2 us per walk; 64 unrolled steps cost
+            // short walks three times what they need): entries past n_it are never read, and a round shorter than
+            // 64 is the walk's last, so the carry is not needed after it either.
             float v = carry;
             chain[lane][0] = (int16_t)(int)v;  // alt:468
+            for (int q0 = 0; q0 < n_it; q0 += 16) {
 #pragma unroll
-            for (int q = 1; q <= 64; q++) {
-                v = v + step_mine;
-                chain[lane][q] = (int16_t)(int)v;
+                for (int k = 1; k <= 16; k++) {
+                    v = v + step_mine;
+                    chain[lane][q0 + k] = (int16_t)(int)v;
+                }
             }
             carry = v;
         }
@@ -1378,10 +1380,15 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
 template <bool DBG>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid_dev g, par_render_args a) {
     stamp(g, DBG ? a.flags : 0u, 3, 0);
+    const unsigned long long core0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
     const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
     render_items<DBG>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
     stamp(g, DBG ? a.flags : 0u, 3, 7);
+    if (DBG && g.stamps && (a.flags & (1u << 29)) && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
+        // slot 5: the wavefront's life in shader-clock cycles (s_memtime), beside slots 0 / 7 in 100 MHz ticks
+        g.stamps[((size_t)3 * PAR_STAMP_WGS + blockIdx.x) * PAR_STAMP_SLOTS + 5] = __builtin_amdgcn_s_memtime() - core0;
+    }
 }
 
 // The columns that overflowed their record (columns_kernel lists them), or every column when a.dense

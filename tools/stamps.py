@@ -54,6 +54,10 @@ if ok3.any():
     for i in range(1, 6):
         d = x3[ok3, idx3[i]] - x3[ok3, idx3[i - 1]]
         print(f"   {names3[i-1]:>20s} -> {names3[i]:<20s}: median {np.median(d):5.2f}  p90 {np.percentile(d,90):5.2f}  max {d.max():5.2f} us")
+    cyc = buf.reshape(5, 8192, 8)[3][ok3, 5].astype(np.float64)
+    life = x3[ok3, 7] - x3[ok3, 0]
+    print(f"   shader clock while a render wavefront lives: median {np.median(cyc / life):.0f} MHz "
+          f"({np.median(cyc):.0f} cycles in {np.median(life):.2f} us)")
 x2 = st[2][:ncol]
 ok = (x2[:, 5] > 0) & (x2[:, 6] > 0)
 print(f"first walk of a column ({ok.sum()} columns): A done -> chain computed median {np.median(x2[ok,5]-x2[ok,2]):.2f} p90 {np.percentile(x2[ok,5]-x2[ok,2],90):.2f}; "
