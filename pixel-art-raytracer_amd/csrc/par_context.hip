@@ -1101,7 +1101,7 @@ static int par_read_grid_impl(par_context* ctx, int32_t* count, int32_t* map, pa
 
 
 // Test hook: the reference's three arithmetic units as the DEVICE computes them (slab_hit, color_scale,
-// normalize_l1 of par_kernels.hip) on host vectors. See par_raytracer.h.
+// normalize_l1_and_inverse of par_kernels.hip) on host vectors. See par_raytracer.h.
 static int par_debug_units_impl(int device, int kind, const void* in_a, const void* in_b, int n, void* out) {
     if (kind < 0 || kind > 2 || n < 0 || !in_a || !out || (kind == 0 && !in_b)) return PAR_ERR_INVALID_ARG;
     par_context* ctx = nullptr;  // (PAR_HIP reports through it)

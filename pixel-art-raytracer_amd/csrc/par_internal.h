@@ -200,7 +200,7 @@ hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& 
 hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                       hipStream_t stream);
 
-// Test hook: the device functions slab_hit / color_scale / normalize_l1 on caller-supplied vectors (device pointers).
+// Test hook: the device functions slab_hit / color_scale / normalize_l1_and_inverse on caller-supplied vectors (device pointers).
 hipError_t par_launch_units(int kind, const void* in_a, const void* in_b, int n, void* out, hipStream_t stream);
 
 #endif

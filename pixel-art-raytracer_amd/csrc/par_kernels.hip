@@ -22,6 +22,7 @@
 // division; min/max are the ?: forms of std::min/std::max so NaN handling follows the reference (first argument
 // wins). With that every float the reference computes is reproduced bit for bit.
 #include "par_internal.h"
+#include "par_fastdiv.h"
 
 #include <limits.h>
 
@@ -307,12 +308,32 @@ __device__ __forceinline__ uint32_t color_scale(uint32_t c, float v) {
     return r | (g << 8) | (b << 16) | (c & 0xFF000000u);
 }
 
-// Vector<float>::normalize, spr:28-35: divides by the L1 length (abs(x) + abs(y)) + abs(z).
-__device__ __forceinline__ void normalize_l1(float x, float y, float z, float& nx, float& ny, float& nz) {
-    const float len = __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z);
-    nx = x / len;
-    ny = y / len;
-    nz = z / len;
+// Vector<float>::normalize, spr:28-35 — divides by the L1 length (abs(x) + abs(y)) + abs(z) — and the inverse
+// direction 1 / n (alt:717-719), through the short sequences of par_fastdiv.h when every
+// lane's operands are in the range they are exact on (components that are integers of magnitude <= 65535 — the
+// caller's are differences of integers — and a length >= 1), through the ordinary divisions otherwise (a light on
+// the pixel: 0 / 0; sprite depths that throw a pixel far out). Wave-uniform choice: one branch, no divergence.
+__device__ __forceinline__ void normalize_l1_and_inverse(float x, float y, float z, float& nx, float& ny, float& nz,
+                                                         float& ix, float& iy, float& iz) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
+    const float len = ax + ay + az;
+    const bool in_range = ax <= PAR_FASTDIV_MAX_NUM && ay <= PAR_FASTDIV_MAX_NUM && az <= PAR_FASTDIV_MAX_NUM && len >= 1.0f;
+    if (__all(in_range)) {
+        const float r = __builtin_amdgcn_rcpf(len);
+        nx = par_fast_div(x, len, r);
+        ny = par_fast_div(y, len, r);
+        nz = par_fast_div(z, len, r);
+        ix = par_fast_rcp(nx);
+        iy = par_fast_rcp(ny);
+        iz = par_fast_rcp(nz);
+    } else {
+        nx = x / len;
+        ny = y / len;
+        nz = z / len;
+        ix = 1.f / nx;
+        iy = 1.f / ny;
+        iz = 1.f / nz;
+    }
 }
 
 // Trunc-toward-zero division by the bin size through a precomputed reciprocal: exact for |n| * B < 2^32
@@ -680,9 +701,8 @@ __global__ __launch_bounds__(256) void bgline_kernel(par_grid_dev g, par_render_
     const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
     // towards_light = normalize_L1(light - (x, 0, 0)), alt:711-715 + spr:28-35
     const float dx = (float)(dyn.lx - x), dy = (float)(dyn.ly - 0), dz = (float)(dyn.lz - 0);
-    float tx, ty, tz;
-    normalize_l1(dx, dy, dz, tx, ty, tz);
-    const float inv_x = 1.f / tx, inv_y = 1.f / ty, inv_z = 1.f / tz;  // alt:717-719
+    float tx, ty, tz, inv_x, inv_y, inv_z;
+    normalize_l1_and_inverse(dx, dy, dz, tx, ty, tz, inv_x, inv_y, inv_z);  // alt:711-719
     const int ox = (int)(int16_t)x;                                    // alt:720-722
     const int bx = div_bin(x, a.magic_b), sy = a.H / a.B;              // alt:724-727
     bool lit = true;
@@ -1098,8 +1118,7 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
         const float dx = (float)(dyn.lx - wx), dy = (float)(dyn.ly - wy), dz = (float)(dyn.lz - wz);
         float tx, ty, tz;
-        normalize_l1(dx, dy, dz, tx, ty, tz);
-        inv_x = 1.f / tx; inv_y = 1.f / ty; inv_z = 1.f / tz;              // alt:717-719
+        normalize_l1_and_inverse(dx, dy, dz, tx, ty, tz, inv_x, inv_y, inv_z);  // alt:711-719
         const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
         const float diffuse = std_max(0.f, dot);                           // alt:745
         b_lit = std_min(1.f, diffuse + ambient);                           // alt:758
@@ -1460,7 +1479,8 @@ __global__ __launch_bounds__(256) void units_kernel(int kind, const void* in_a, 
     } else {
         const float* v = static_cast<const float*>(in_a) + (size_t)i * 3;
         float* o = static_cast<float*>(out) + (size_t)i * 3;
-        normalize_l1(v[0], v[1], v[2], o[0], o[1], o[2]);
+        float ix, iy, iz;  // (the same function the shading uses: short sequences where they are exact)
+        normalize_l1_and_inverse(v[0], v[1], v[2], o[0], o[1], o[2], ix, iy, iz);
     }
 }
 

@@ -167,7 +167,7 @@ def test_errors(par, T):
 
 def test_device_units_equal_the_reference(par, T):
     """AABB::intersect (alt:40-83), Color::operator* (spr:8-16) and Vector::normalize (spr:28-35) as the DEVICE
-    kernels compute them (slab_hit, color_scale, normalize_l1 through the par_debug_units hook) on the unit vectors
+    kernels compute them (slab_hit, color_scale, normalize_l1_and_inverse through the par_debug_units hook) on the unit vectors
     tests/golden/ref_units.npz holds, against the answers the reference's own compiled functions gave for them:
     4 096 + 2 048 + 2 048 results, bit for bit (NaN payloads and +-inf inverse directions included)."""
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_units.npz"))
@@ -180,3 +180,19 @@ def test_device_units_equal_the_reference(par, T):
     assert np.array_equal(cs, z["cs_out"])
     nv = par.debug_units(2, z["nv"].astype(np.float32))
     assert nv.tobytes() == z["nv_out"].astype(np.float32).tobytes()
+
+
+def test_short_division_sequences_are_exact(tmp_path):
+    """The shading's six divisions per pixel run as a reciprocal plus two or three fused refinements
+    (csrc/par_fastdiv.h) wherever the operands are in the range on which that is EXACTLY the IEEE quotient. That
+    range is checked exhaustively here, on the GPU, by tools/divcheck.hip built from the same header: every a / b
+    with integers |a| <= 65535, 1 <= b <= 196605, |a| <= b (2 x 10^10 quotients), and 1 / t for every float t with
+    2^-24 <= |t| <= 2^24, +-0, +-inf and all NaNs, against hipcc's correctly rounded division."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "divcheck")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-Wno-unused-result",
+                    "-o", exe, os.path.join(root, "tools", "divcheck.hip")], check=True, capture_output=True, timeout=300)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count(": 0 mismatches") == 2, p.stdout
