@@ -1053,11 +1053,15 @@ static int par_get_stats_impl(par_context* ctx, par_frame_stats* stats) {
     ctx->stats.bin_insertions = ctx->total_pairs;
     ctx->stats.shadow_rays = -1;
     {
-        int32_t nc[2] = {0, 0};
-        static_assert(PAR_CNT_COLS == 0 && PAR_CNT_SLOW == 1, "read together");
+        int32_t nc[3] = {0, 0, 0};
+        static_assert(PAR_CNT_COLS == 0 && PAR_CNT_SLOW == 1 && PAR_CNT_ERROR == 2, "read together");
         PAR_HIP(hipMemcpy(nc, ctx->grid.counters, sizeof(nc), hipMemcpyDeviceToHost));
         ctx->stats.occupied_columns = nc[0];
         ctx->stats.overflow_columns = nc[1];
+        if (nc[2] != 0) {
+            return fail(ctx, PAR_ERR_HIP, "the hash build's barrier timed out in the last frame (a build workgroup "
+                                          "never arrived): that frame is not valid");
+        }
     }
     if (ctx->last_flags & PAR_RENDER_COUNT_RAYS) {
         unsigned long long v = 0;
