@@ -1670,10 +1670,24 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
     return hipSuccess;
 }
 
-// One wavefront per work item of the host's bound (rounded up to whole workgroups and to a multiple of the shard
-// count, which render_items' item-to-wavefront mapping needs).
+// One wavefront per work item of the host's bound, or per few of them (rounded up to whole workgroups and to a
+// multiple of the shard count, which render_items' item-to-wavefront mapping needs).
 static int64_t item_workgroups(int64_t item_bound) {
     const int64_t unit = PAR_ITEM_SHARDS > PAR_WAVE_NW ? PAR_ITEM_SHARDS : PAR_WAVE_NW;
+    // Frames with very many items (dense scenes: 260 000 at 4096^2) are rendered by wavefronts that take several items
+    // one after the other: launching a wavefront costs the chip more than its loop's extra iteration (full floor:
+    // 382 us with one item per wavefront, 353 with 8, 347 with 16, 345 with 32), while a frame with few items needs
+    // every wavefront it can get (480x320 graybox, 2 400 items: 11.8 us with one, 16.7 with 4). PAR_TUNE_ITEMS_PER_WAVE
+    // overrides (tools).
+    static const int tuned = [] {
+        const char* e = std::getenv("PAR_TUNE_ITEMS_PER_WAVE");
+        const int v = e ? std::atoi(e) : 0;
+        return v < 0 ? 0 : (v > 64 ? 64 : v);
+    }();
+    int64_t per_wave = tuned > 0 ? tuned : item_bound / 16384;
+    if (per_wave < 1) per_wave = 1;
+    if (per_wave > 16) per_wave = 16;
+    item_bound = (item_bound + per_wave - 1) / per_wave;
     int64_t waves = (item_bound + unit - 1) / unit * unit;
     if (waves < unit) waves = unit;
     if (waves > (int64_t)1 << 24) waves = (int64_t)1 << 24;  // (the wavefronts then loop over their shard)
