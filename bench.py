@@ -101,8 +101,8 @@ def time_blocks(run_block, steps, blocks, barrier, reduce_max):
     for _ in range(blocks):
         barrier()
         t0 = time.perf_counter()
-        run_block(first, steps)
-        barrier()
+        run_block(first, steps)   # ends with torch.cuda.synchronize() (N = 1) / the drained pipeline (N > 1)
+        barrier(after_block=True)
         out.append(reduce_max(time.perf_counter() - t0) / steps * 1e3)
         first += steps
     return out
@@ -249,14 +249,17 @@ def main():
         """Exactly n steps, drained."""
         if gather is None:
             pipe.submit_many(first, n, flags)  # the swap chain's loop runs in the library, one call
+            torch.cuda.synchronize()           # (one device-wide wait: every slot's stream is done)
         else:
             for i in range(first, first + n):
                 step(i, flags)
-        drain()
+            drain()
 
-    def barrier():
+    def barrier(after_block=False):
         if world > 1:
             dist.barrier()
+        elif after_block:
+            return  # (N = 1: run_block has just synchronised the device; nothing else could be running)
         torch.cuda.synchronize()
 
     def reduce_max(x):
