@@ -14,6 +14,17 @@
 
 #include "par_internal.h"
 
+// The bins one entity is inserted into (cull and ranges of alt:202-240, computed once per AABB the host is given):
+// bin columns [x0, x1) x [y0, y1), nz bins deep; empty when x1 <= x0. Everything the host sizes launches and lists
+// with follows from it.
+struct par_footprint {
+    int16_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    int32_t nz = 0;
+    int32_t items = 0;  // render work items (64-pixel chunks) the entity can cause, see footprint_of
+    int32_t cols() const { return (x1 - x0) * (y1 - y0); }
+    int64_t pairs() const { return (int64_t)cols() * nz; }  // (entity, bin) insertions, alt:243-267
+};
+
 struct par_context {
     par_params params{};
     int device = 0;
@@ -22,11 +33,10 @@ struct par_context {
 
     // host mirrors
     std::vector<par_aabb> h_aabbs;
-    std::vector<int32_t> h_pairs;  // (entity, bin) pairs each entity inserts, alt:243-267
+    std::vector<par_footprint> h_fp;  // per entity: the bins it is inserted into (alt:202-240) and what follows from them
     int64_t total_pairs = 0;
-    std::vector<int32_t> h_cols;   // screen columns (bx, by) each entity reaches: its pairs without the z factor
     int64_t total_cols = 0;        // >= the occupied columns of the frame
-    int64_t total_items = 0;       // >= the render work items (64-pixel chunks) of the frame, see items_of
+    int64_t total_items = 0;       // >= the render work items (64-pixel chunks) of the frame, see footprint_of
     std::vector<int32_t> h_colpairs;  // (entity, bin) pairs per screen column (>= its occupied bins, >= its entries)
     int64_t cols_over = 0;            // columns with more pairs than a column record is sure to hold
     int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
@@ -122,48 +132,77 @@ int hip_fail(par_context* c, hipError_t e, const char* what) {
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
     } while (0)
 
-// (entity, bin) pairs one AABB inserts: the cull and range math of alt:202-240. `cols`: the (bx, by) columns among them.
-int64_t pairs_of(const par_context* c, const par_aabb& a, int32_t* cols = nullptr) {
-    if (cols) *cols = 0;
+// The cull and range math of alt:202-240 for one AABB. `items`: the render work items it can cause: its sprite
+// rectangle (ex wide, ey + ez tall, alt:310-317) is cut by the screen columns it reaches into that many pieces, each
+// visited in whole 64-pixel chunks: sum of ceil(area_i / 64) <= floor(area / 64) + pieces. (A column switches to
+// visiting its whole tile only when that takes fewer chunks.)
+par_footprint footprint_of(const par_context* c, const par_aabb& a) {
+    par_footprint f;
     const int W = c->params.width, H = c->params.height, L = c->params.length, B = c->params.bin_size;
     const int minx = a.px, miny = a.py, minz = a.pz;
     const int maxx = minx + a.ex, maxy = miny + a.ey, maxz = minz + a.ez;
     if ((maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) || (maxz < -a.ez - B) ||
         (minz > L + B)) {
-        return 0;
+        return f;
     }
     const int x0 = std::max(0, minx / B), y0 = std::max(0, (H - maxy - maxz) / B), z0 = std::max(0, minz / B);
     const int x1 = std::min(c->gx, (maxx + B - 1) / B), y1 = std::min(c->gy, (H - miny - minz + B - 1) / B);
     const int z1 = std::min(c->gz, (maxz + B - 1) / B);
-    if (x1 <= x0 || y1 <= y0 || z1 <= z0) return 0;
-    if (cols) *cols = (x1 - x0) * (y1 - y0);
-    return (int64_t)(x1 - x0) * (y1 - y0) * (z1 - z0);
+    if (x1 <= x0 || y1 <= y0 || z1 <= z0) return f;
+    f.x0 = (int16_t)x0; f.x1 = (int16_t)x1; f.y0 = (int16_t)y0; f.y1 = (int16_t)y1;
+    f.nz = z1 - z0;
+    f.items = (int32_t)((int)a.ex * ((int)a.ey + (int)a.ez) / 64 + f.cols());
+    return f;
 }
 
-// Adds (sign = +1) or removes (-1) an AABB's pairs in the per-column histogram. A column whose pairs exceed
+// Adds (sign = +1) or removes (-1) a footprint's pairs in the per-column histogram. A column whose pairs exceed
 // PAR_COL_NB (<= PAR_COL_ENT) may overflow its record; while there is none, no column can, and the frame needs no
 // launch for the overflow list.
-void col_hist(par_context* c, const par_aabb& a, int sign) {
-    const int W = c->params.width, H = c->params.height, L = c->params.length, B = c->params.bin_size;
-    const int minx = a.px, miny = a.py, minz = a.pz;
-    const int maxx = minx + a.ex, maxy = miny + a.ey, maxz = minz + a.ez;
-    if ((maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) || (maxz < -a.ez - B) ||
-        (minz > L + B)) {
-        return;
-    }
-    const int x0 = std::max(0, minx / B), y0 = std::max(0, (H - maxy - maxz) / B), z0 = std::max(0, minz / B);
-    const int x1 = std::min(c->gx, (maxx + B - 1) / B), y1 = std::min(c->gy, (H - miny - minz + B - 1) / B);
-    const int z1 = std::min(c->gz, (maxz + B - 1) / B);
-    if (x1 <= x0 || y1 <= y0 || z1 <= z0) return;
+void col_hist(par_context* c, const par_footprint& f, int sign) {
     constexpr int kSure = PAR_COL_NB < PAR_COL_ENT ? PAR_COL_NB : PAR_COL_ENT;
-    for (int x = x0; x < x1; x++) {
-        for (int y = y0; y < y1; y++) {
+    for (int x = f.x0; x < f.x1; x++) {
+        for (int y = f.y0; y < f.y1; y++) {
             int32_t& n = c->h_colpairs[(size_t)x * c->gy + y];
             const bool was = n > kSure;
-            n += sign * (z1 - z0);
+            n += sign * f.nz;
             c->cols_over += (int)(n > kSure) - (int)was;
         }
     }
+}
+
+// What an update of aabbs[first, first + n) does to the host's bookkeeping, in two steps: `plan` computes the new
+// footprints and totals (so that the caller can grow pools or refuse before anything changes), `commit` applies them.
+struct par_update_plan {
+    std::vector<par_footprint> fp;
+    int64_t pairs = 0, cols = 0, items = 0;  // the new totals
+};
+
+void plan_update(const par_context* c, const par_aabb* aabbs, int first, int n, par_update_plan* plan) {
+    plan->fp.resize((size_t)n);
+    plan->pairs = c->total_pairs;
+    plan->cols = c->total_cols;
+    plan->items = c->total_items;
+    for (int i = 0; i < n; i++) {
+        const par_footprint f = footprint_of(c, aabbs[i]);
+        const par_footprint& old = c->h_fp[(size_t)(first + i)];
+        plan->fp[(size_t)i] = f;
+        plan->pairs += f.pairs() - old.pairs();
+        plan->cols += f.cols() - old.cols();
+        plan->items += f.items - old.items;
+    }
+}
+
+void commit_update(par_context* c, const par_aabb* aabbs, int first, int n, const par_update_plan& plan) {
+    for (int i = 0; i < n; i++) {
+        par_footprint& slot = c->h_fp[(size_t)(first + i)];
+        col_hist(c, slot, -1);
+        col_hist(c, plan.fp[(size_t)i], +1);
+        slot = plan.fp[(size_t)i];
+        c->h_aabbs[(size_t)(first + i)] = aabbs[i];
+    }
+    c->total_pairs = plan.pairs;
+    c->total_cols = plan.cols;
+    c->total_items = plan.items;
 }
 
 bool extent_ok(const par_aabb& a) {
@@ -171,15 +210,7 @@ bool extent_ok(const par_aabb& a) {
     return a.ex >= 0 && a.ey >= 0 && a.ez >= 0 && a.ex <= PAR_SPRITE_W && (int)a.ey + (int)a.ez <= PAR_SPRITE_H;
 }
 
-// Render work items (64-pixel chunks) an entity can cause: its sprite rectangle (ex wide, ey + ez tall, alt:310-317)
-// is cut by the `cols` screen columns it reaches into that many pieces, each visited in whole chunks:
-// sum of ceil(area_i / 64) <= floor(area / 64) + pieces. (A column switches to visiting its whole tile only when that
-// takes fewer chunks.)
-int64_t items_of(const par_aabb& a, int32_t cols) {
-    return cols > 0 ? (int64_t)a.ex * ((int)a.ey + (int)a.ez) / 64 + cols : 0;
-}
-
-// ... and what a frame can hold at most: every column visited as a whole tile.
+// What a frame can hold at most of render work items: every column visited as a whole tile.
 int64_t max_items(const par_context* c) {
     const int64_t B = c->params.bin_size;
     return (int64_t)c->gx * c->gy * ((B * B + 63) / 64);
@@ -667,15 +698,15 @@ static int par_set_entities_impl(par_context* ctx, const par_aabb* aabbs, const 
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
     drop_graphs(ctx);
-    std::vector<int32_t> pairs((size_t)n), cols((size_t)n);
+    std::vector<par_footprint> fps((size_t)n);
     int64_t total = 0, total_cols = 0, total_items = 0;
     for (int i = 0; i < n; i++) {
-        const int64_t k = pairs_of(ctx, aabbs[i], &cols[(size_t)i]);
-        if (k > 0x7FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "entity spans too many bins");
-        pairs[(size_t)i] = (int32_t)k;
-        total += k;
-        total_cols += cols[(size_t)i];
-        total_items += items_of(aabbs[i], cols[(size_t)i]);
+        const par_footprint f = footprint_of(ctx, aabbs[i]);
+        if (f.pairs() > 0x7FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "entity spans too many bins");
+        fps[(size_t)i] = f;
+        total += f.pairs();
+        total_cols += f.cols();
+        total_items += f.items;
     }
     int rc = ensure_pool(ctx, total);
     if (rc != PAR_OK) return rc;
@@ -698,10 +729,9 @@ static int par_set_entities_impl(par_context* ctx, const par_aabb* aabbs, const 
     ctx->h_aabbs.assign(aabbs, aabbs + n);
     ctx->h_colpairs.assign((size_t)ctx->gx * ctx->gy, 0);
     ctx->cols_over = 0;
-    for (int i = 0; i < n; i++) col_hist(ctx, aabbs[i], +1);
-    ctx->h_pairs.swap(pairs);
+    for (int i = 0; i < n; i++) col_hist(ctx, fps[(size_t)i], +1);
+    ctx->h_fp.swap(fps);
     ctx->total_pairs = total;
-    ctx->h_cols.swap(cols);
     ctx->total_cols = total_cols;
     ctx->total_items = total_items;
     ctx->n_entities = n;
@@ -756,23 +786,15 @@ static int par_update_aabbs_impl(par_context* ctx, const par_aabb* aabbs, int fi
     if (!ctx || !aabbs || first < 0 || n < 0 || !ctx->have_entities || first + n > ctx->n_entities) {
         return fail(ctx, PAR_ERR_INVALID_ARG, "update range outside the uploaded entities");
     }
-    int64_t total = ctx->total_pairs;
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    std::vector<int32_t> np((size_t)n), nc((size_t)n);
-    int64_t total_cols = ctx->total_cols, total_items = ctx->total_items;
-    for (int i = 0; i < n; i++) {
-        np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i], &nc[(size_t)i]);
-        total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
-        total_cols += nc[(size_t)i] - ctx->h_cols[(size_t)(first + i)];
-        total_items += items_of(aabbs[i], nc[(size_t)i]) -
-                       items_of(ctx->h_aabbs[(size_t)(first + i)], ctx->h_cols[(size_t)(first + i)]);
-    }
+    par_update_plan plan;
+    plan_update(ctx, aabbs, first, n, &plan);
     PAR_HIP(hipSetDevice(ctx->device));
-    int rc = ensure_pool(ctx, total);
+    int rc = ensure_pool(ctx, plan.pairs);
     if (rc != PAR_OK) return rc;
-    rc = ensure_items(ctx, total_items, total_cols);
+    rc = ensure_items(ctx, plan.items, plan.cols);
     if (rc != PAR_OK) return rc;
     // a frame enqueued asynchronously by par_render_device may still be reading the AABBs: wait for it
     if (ctx->has_last_stream) PAR_HIP(hipStreamSynchronize(ctx->last_stream));
@@ -782,16 +804,7 @@ static int par_update_aabbs_impl(par_context* ctx, const par_aabb* aabbs, int fi
     }
     PAR_HIP(hipMemcpyAsync(ctx->d_aabbs + first, aabbs, (size_t)n * sizeof(par_aabb), hipMemcpyHostToDevice, ctx->stream));
     PAR_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < n; i++) {
-        col_hist(ctx, ctx->h_aabbs[(size_t)(first + i)], -1);
-        col_hist(ctx, aabbs[i], +1);
-        ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
-        ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
-        ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
-    }
-    ctx->total_pairs = total;
-    ctx->total_cols = total_cols;
-    ctx->total_items = total_items;
+    commit_update(ctx, aabbs, first, n, plan);
     mark_staged(ctx, first, n);  // (a captured graph uploads the scene from its staging area)
     return PAR_OK;
 }
@@ -804,19 +817,12 @@ static int par_update_aabbs_async_impl(par_context* ctx, const par_aabb* aabbs, 
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    int64_t total = ctx->total_pairs, total_cols = ctx->total_cols, total_items = ctx->total_items;
-    std::vector<int32_t> np((size_t)n), nc((size_t)n);
-    for (int i = 0; i < n; i++) {
-        np[(size_t)i] = (int32_t)pairs_of(ctx, aabbs[i], &nc[(size_t)i]);
-        total += np[(size_t)i] - ctx->h_pairs[(size_t)(first + i)];
-        total_cols += nc[(size_t)i] - ctx->h_cols[(size_t)(first + i)];
-        total_items += items_of(aabbs[i], nc[(size_t)i]) -
-                       items_of(ctx->h_aabbs[(size_t)(first + i)], ctx->h_cols[(size_t)(first + i)]);
-    }
+    par_update_plan plan;
+    plan_update(ctx, aabbs, first, n, &plan);
     PAR_HIP(hipSetDevice(ctx->device));
     // the node pool and the item list grow rarely; that path frees device memory and has to wait for everything in
     // flight
-    if (total > ctx->grid.capacity || !items_fit(ctx, total_items, total_cols)) {
+    if (plan.pairs > ctx->grid.capacity || !items_fit(ctx, plan.items, plan.cols)) {
         return par_update_aabbs(ctx, aabbs, first, n);
     }
     // frames enqueued on another stream are not ordered with this copy: wait for them
@@ -839,16 +845,7 @@ static int par_update_aabbs_async_impl(par_context* ctx, const par_aabb* aabbs, 
     PAR_HIP(hipEventRecord(ctx->ev_update, stream));
     ctx->ev_update_pending = true;
     ctx->update_stream = stream;
-    for (int i = 0; i < n; i++) {
-        col_hist(ctx, ctx->h_aabbs[(size_t)(first + i)], -1);
-        col_hist(ctx, aabbs[i], +1);
-        ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
-        ctx->h_pairs[(size_t)(first + i)] = np[(size_t)i];
-        ctx->h_cols[(size_t)(first + i)] = nc[(size_t)i];
-    }
-    ctx->total_pairs = total;
-    ctx->total_cols = total_cols;
-    ctx->total_items = total_items;
+    commit_update(ctx, aabbs, first, n, plan);
     mark_staged(ctx, first, n);  // (a captured graph uploads the scene from its staging area)
     return PAR_OK;
 }
@@ -974,26 +971,15 @@ static int par_graph_capture_impl(par_context* ctx, void* stream_v, int row_begi
 static int par_graph_stage_impl(par_context* ctx, const par_aabb* aabbs, int first, int n, const par_light* light) {
     if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
     if (n < 0 || first < 0 || first + n > ctx->n_entities || (n > 0 && !aabbs)) return fail(ctx, PAR_ERR_INVALID_ARG, "stage range");
-    int64_t total = ctx->total_pairs;
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
-        total += pairs_of(ctx, aabbs[i]) - ctx->h_pairs[(size_t)(first + i)];
     }
-    if (total > ctx->graph_pair_bound || total > ctx->grid.capacity) {
+    par_update_plan plan;
+    plan_update(ctx, aabbs, first, n, &plan);
+    if (plan.pairs > ctx->graph_pair_bound || plan.pairs > ctx->grid.capacity) {
         return fail(ctx, PAR_ERR_UNSUPPORTED, "staged frame exceeds what the captured graph was sized for; capture again");
     }
-    for (int i = 0; i < n; i++) {
-        int32_t nc = 0;
-        ctx->h_pairs[(size_t)(first + i)] = (int32_t)pairs_of(ctx, aabbs[i], &nc);
-        ctx->total_items += items_of(aabbs[i], nc) -
-                            items_of(ctx->h_aabbs[(size_t)(first + i)], ctx->h_cols[(size_t)(first + i)]);
-        ctx->total_cols += nc - ctx->h_cols[(size_t)(first + i)];
-        ctx->h_cols[(size_t)(first + i)] = nc;
-        col_hist(ctx, ctx->h_aabbs[(size_t)(first + i)], -1);
-        col_hist(ctx, aabbs[i], +1);
-        ctx->h_aabbs[(size_t)(first + i)] = aabbs[i];
-    }
-    ctx->total_pairs = total;
+    commit_update(ctx, aabbs, first, n, plan);
     mark_staged(ctx, first, n);  // (the staging areas are brought up to date by par_graph_launch)
     if (light) ctx->light = *light;
     return PAR_OK;
@@ -1011,7 +997,7 @@ static int par_graph_launch_impl(par_context* ctx, void* stream) {
     // This graph's staging area: free once its previous launch has run (its copy nodes read the area when they
     // execute, not when the graph is launched), then brought up to date with the host mirror and the light.
     if (ctx->ev_graph_pending[s]) {
-        PAR_HIP(hipEventSynchronize(ctx->ev_graph[s]));
+        if (hipEventQuery(ctx->ev_graph[s]) != hipSuccess) PAR_HIP(hipEventSynchronize(ctx->ev_graph[s]));
         ctx->ev_graph_pending[s] = false;
     }
     if (ctx->stage_hi[s] > ctx->stage_lo[s]) {
