@@ -43,7 +43,11 @@ enum {
      * this on implicitly because the result then is observable. */
     PAR_RENDER_TRACE_BACKGROUND = 1u << 0,
     /* Count the shadow rays actually traced into par_frame_stats (one atomic per workgroup). */
-    PAR_RENDER_COUNT_RAYS = 1u << 1
+    PAR_RENDER_COUNT_RAYS = 1u << 1,
+    /* This frame is one of several in flight on the device (a swap chain, par_render_device_slots): favour the
+     * device's throughput over the frame's own latency (one wavefront per screen column builds its record and does
+     * all its shadow walks, instead of two sharing the walks). Same pixels either way. */
+    PAR_RENDER_PIPELINED = 1u << 2
     /* Bit 22 (tests): no self-contained work items, every column is rendered from its record; same pixels.
      * Bit 23 (tests): build the spatial hash with two launches even where one would do; same pixels.
      * Bits 24-28 switch parts of the frame OFF for timing experiments (tools/ablate.py, tools/overlap.py): the output

@@ -27,6 +27,7 @@ STATUS_NAMES = {0: "PAR_OK", 1: "PAR_ERR_INVALID_ARG", 2: "PAR_ERR_NO_DEVICE", 3
                 5: "PAR_ERR_UNSUPPORTED", 6: "PAR_ERR_EXTENT", 7: "PAR_ERR_SPRITE_ID", 8: "PAR_ERR_NOT_READY"}
 RENDER_TRACE_BACKGROUND = 1 << 0
 RENDER_COUNT_RAYS = 1 << 1
+RENDER_PIPELINED = 1 << 2
 
 # every symbol include/par_raytracer.h declares
 ABI_SYMBOLS = (

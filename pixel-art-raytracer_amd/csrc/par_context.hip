@@ -1125,6 +1125,7 @@ static int par_render_device_slots_impl(par_context* const* ctxs, void* const* s
                                         int n_slots, int row_begin, int row_end, int first_frame, int n_frames,
                                         unsigned flags) {
     if (!ctxs || !streams || !device_outs || n_slots < 1 || n_frames < 0 || first_frame < 0) return PAR_ERR_INVALID_ARG;
+    if (n_slots > 1) flags |= PAR_RENDER_PIPELINED;  // several frames in flight: throughput before latency
     for (int f = first_frame; f < first_frame + n_frames; f++) {
         const int k = f % n_slots;
         const int rc = par_render_device(ctxs[k], streams[k], row_begin, row_end, &device_outs[k], flags);

@@ -60,9 +60,7 @@ struct par_colrec {
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");
 static_assert((PAR_COL_NB & (PAR_COL_NB - 1)) == 0 && PAR_COL_NB <= 64, "one occupied bin per lane");
-constexpr int PAR_COL_ROLES = 2;         // wavefronts that share the shadow walks of one column
-constexpr int PAR_COL_WAVES = PAR_COL_ROLES;  // wavefronts per columns_kernel workgroup: those of one column
-static_assert(PAR_COL_WAVES % PAR_COL_ROLES == 0 && PAR_COL_WALK % PAR_COL_ROLES == 0, "column workgroup layout");
+static_assert(PAR_COL_WALK % 2 == 0, "two wavefronts may share a column's walks, each with half of the walk area");
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world
 // position (x, 0, 0) (alt:281, 707-709), so its ray starts in bin (x / B, H / B, 0) whatever its row -- one walk per

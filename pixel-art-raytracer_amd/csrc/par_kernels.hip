@@ -26,6 +26,7 @@
 
 #include <limits.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -474,6 +475,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // occupied bins r, r + roles, ... and the r-th part of the record's walk area); role 0 does everything else. The
 // others repeat the scan of the column's counts (they need the list of occupied bins) and leave at once when the
 // column has no walk for them.
+template <int ROLES>
 __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_render_args& a, ColWave& sm,
                                              int32_t* others_found, int ci, int role, int n_cols_bound) {
     const int lane = (int)threadIdx.x & 63;
@@ -566,13 +568,13 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     if (lane == 0 && n_items > 0) item_base = atomicAdd(&g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], n_items);
 
     // ---- B: the shadow walks of this wavefront's share of the occupied bins, one after the other ---------------
-    constexpr int kWalkPart = PAR_COL_WALK / PAR_COL_ROLES;
+    constexpr int kWalkPart = PAR_COL_WALK / ROLES;
     const int walk_lo = role * kWalkPart;
     int n_walk = 0;
     bool walk_failed = false;
     if (!overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
         const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
-        for (int i = role; i < n_nb; i += PAR_COL_ROLES) {
+        for (int i = role; i < n_nb; i += ROLES) {
             const int sz = sm.nb[i].bz;
             const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, sm.chain, sm.stage, i == 0 ? a.flags : 0u);
             if (n_rec < 0 || n_walk + n_rec > kWalkPart) {
@@ -600,14 +602,14 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     // workgroup, and all of them are still here exactly when the column has a walk for each (the same test in all
     // of them): then, and only then, they meet at a barrier.
     bool walks_empty = n_walk == 0 && !walk_failed;
-    if (!overflow && n_nb >= PAR_COL_ROLES) {
-        static_assert(PAR_COL_ROLES == 2, "one other wavefront writes the word");
+    if (ROLES > 1 && !overflow && n_nb >= ROLES) {
+        static_assert(ROLES <= 2, "one other wavefront writes the word");
         if (role != 0 && lane == 0) *others_found = walks_empty ? 0 : 1;
         __syncthreads();
         if (role == 0) walks_empty = walks_empty && *others_found == 0;
     }
     if (role != 0) {  // the other wavefronts' part of the record: the bins they walked from
-        if (ci < g.col_capacity && lane < n_nb && lane % PAR_COL_ROLES == role) g.colrec[ci].nb[lane] = sm.nb[lane];
+        if (ci < g.col_capacity && lane < n_nb && lane % ROLES == role) g.colrec[ci].nb[lane] = sm.nb[lane];
         return;
     }
 
@@ -657,7 +659,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
             rec->dup_hi = (uint32_t)(dup_mask >> 32);
         }
         if (!overflow) {
-            if (lane < n_nb && lane % PAR_COL_ROLES == 0) rec->nb[lane] = sm.nb[lane];
+            if (lane < n_nb && lane % ROLES == 0) rec->nb[lane] = sm.nb[lane];
             if (lane < n_entries) {
                 rec->entries[lane] = sm.entries[lane];
                 rec->ebz[lane] = sm.ebz[lane];
@@ -668,21 +670,33 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     stamp(g, a.flags, 2, 4);
 }
 
-// `n_col_blocks` workgroups of PAR_COL_WAVES columns each; `n_cols_bound` bounds the column list (the wavefronts past
-// it do the background walks when background rays are traced).
+// ROLES = 2 (a frame on its own: latency): a workgroup is the two wavefronts of ONE column (columns_wave's barrier is
+// a workgroup barrier). ROLES = 1 (PAR_RENDER_PIPELINED, a frame among several in flight: throughput): a workgroup
+// is four wavefronts, each with a column of its own and all of that column's walks; the second wavefront of a
+// column is a launch, a scan of the counts and a wavefront slot that most columns of a sparse scene do not need.
+template <int ROLES>
+constexpr int col_waves() { return ROLES == 1 ? 4 : ROLES; }
+
+// `n_cols_bound` bounds the column list (the wavefronts past it do the background walks when background rays are
+// traced).
+template <int ROLES>
 __device__ __forceinline__ void columns_block(const par_grid_dev& g, const par_render_args& a, ColWave* sm,
                                               int32_t* others_found, int block, int n_cols_bound) {
-    static_assert(PAR_COL_WAVES == PAR_COL_ROLES, "a column's wavefronts are its whole workgroup (columns_wave's barrier)");
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
-    columns_wave(g, a, sm[wave], others_found, block, wave, n_cols_bound);
+    if (ROLES == 1) {
+        columns_wave<1>(g, a, sm[wave], others_found, block * col_waves<1>() + wave, 0, n_cols_bound);
+    } else {
+        columns_wave<ROLES>(g, a, sm[wave], others_found, block, wave, n_cols_bound);
+    }
 }
 
-__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_kernel(par_grid_dev g, par_render_args a,
-                                                                      int n_cols_bound) {
-    __shared__ ColWave sm[PAR_COL_WAVES];
+template <int ROLES>
+__global__ __launch_bounds__(col_waves<ROLES>() * 64) void columns_kernel(par_grid_dev g, par_render_args a,
+                                                                           int n_cols_bound) {
+    __shared__ ColWave sm[col_waves<ROLES>()];
     __shared__ int32_t others_found;
-    columns_block(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
+    columns_block<ROLES>(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
     stamp(g, a.flags, 2, 7);
 }
 
@@ -783,13 +797,14 @@ __global__ __launch_bounds__(256) void fill_kernel(par_render_args a, uint32_t o
 // The background fill does not depend on the hash, and it takes about as long as the column records of a
 // 16 Mpixel frame: one launch for both (the first `n_col` workgroups build column records, the others fill), so the
 // fill costs the frame's launch chain neither a link nor its own duration.
-__global__ __launch_bounds__(PAR_COL_WAVES * 64) void columns_fill_kernel(par_grid_dev g, par_render_args a,
-                                                                          uint32_t out_rgba, int n_col_blocks,
-                                                                          int n_cols_bound, int2 part) {
-    __shared__ ColWave sm[PAR_COL_WAVES];
+template <int ROLES>
+__global__ __launch_bounds__(col_waves<ROLES>() * 64) void columns_fill_kernel(par_grid_dev g, par_render_args a,
+                                                                                uint32_t out_rgba, int n_col_blocks,
+                                                                                int n_cols_bound, int2 part) {
+    __shared__ ColWave sm[col_waves<ROLES>()];
     __shared__ int32_t others_found;
     if ((int)blockIdx.x < n_col_blocks) {
-        columns_block(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
+        columns_block<ROLES>(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
     } else {
         stamp(g, a.flags, 2, 0);
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col_blocks, (int)gridDim.x - n_col_blocks, part);
@@ -1598,23 +1613,37 @@ hipError_t par_launch_bin_resolve(const par_grid_dev& g, const par_bin_args& a, 
 }
 
 // Columns of the launch: the occupied columns (at most `column_bound`, at most those of the rendered rows) and, when
-// background rays are traced, one background walk per bin column; PAR_COL_WAVES of them per workgroup.
-static int64_t column_blocks(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, int64_t* n_cols) {
+// background rays are traced, one background walk per bin column; `per_block` of them per workgroup.
+static int64_t column_blocks(const par_grid_dev& g, const par_render_args& a, int64_t column_bound, int per_block,
+                             int64_t* n_cols) {
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
     int64_t n = column_bound < cols_in_range ? column_bound : cols_in_range;
     if (n < 0) n = 0;
     *n_cols = n;
     if (a.trace_bg) n += g.gx;  // the background walks
-    constexpr int kPerBlock = PAR_COL_WAVES / PAR_COL_ROLES;
-    return (n + kPerBlock - 1) / kPerBlock;
+    return (n + per_block - 1) / per_block;
+}
+
+// One wavefront per column instead of two: for a frame among several in flight (PAR_RENDER_PIPELINED) that has
+// enough columns to fill the chip anyway. (4096^2 / 1024 primitives, four in flight: 23.8 against 24.1 us per frame;
+// full floor 330 against 346 us; the 480x320 graybox scene, 94 columns, 13.5 against 12.0 us: few columns need the
+// second wavefront for their walks even then.)
+static bool one_wave_per_column(const par_grid_dev& g, const par_render_args& a, int64_t column_bound) {
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    return (a.flags & PAR_RENDER_PIPELINED) != 0 && std::min(column_bound, cols_in_range) >= 1024;
 }
 
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                               hipStream_t stream) {
+    const bool pipelined = one_wave_per_column(g, a, column_bound);
     int64_t n_cols;
-    const int64_t blocks = column_blocks(g, a, column_bound, &n_cols);
+    const int64_t blocks = column_blocks(g, a, column_bound, pipelined ? col_waves<1>() : 1, &n_cols);
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(columns_kernel, dim3((unsigned)blocks), dim3(PAR_COL_WAVES * 64), 0, stream, g, a, (int)n_cols);
+    if (pipelined) {
+        hipLaunchKernelGGL(columns_kernel<1>, dim3((unsigned)blocks), dim3(col_waves<1>() * 64), 0, stream, g, a, (int)n_cols);
+    } else {
+        hipLaunchKernelGGL(columns_kernel<2>, dim3((unsigned)blocks), dim3(col_waves<2>() * 64), 0, stream, g, a, (int)n_cols);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !a.trace_bg) return e;
     hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
@@ -1624,12 +1653,20 @@ hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, i
 // Column records + the last share of the fill in one launch.
 hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                    const par_fill_plan& fill, hipStream_t stream) {
+    const bool pipelined = one_wave_per_column(g, a, column_bound);
+    const int waves = pipelined ? col_waves<1>() : col_waves<2>();
     int64_t n_cols;
-    const int64_t n_col_blocks = column_blocks(g, a, column_bound, &n_cols);
-    int64_t n_fill = fill_blocks(fill, 2, PAR_COL_WAVES, 4 * PAR_FILL_RIDE_WGS);
+    const int64_t n_col_blocks = column_blocks(g, a, column_bound, pipelined ? col_waves<1>() : 1, &n_cols);
+    // (the same number of fill WAVEFRONTS whatever the workgroup size)
+    int64_t n_fill = fill_blocks(fill, 2, waves, 4 * PAR_FILL_RIDE_WGS * 2 / waves);
     if (n_col_blocks + n_fill <= 0) return hipSuccess;
-    hipLaunchKernelGGL(columns_fill_kernel, dim3((unsigned)(n_col_blocks + n_fill)), dim3(PAR_COL_WAVES * 64), 0, stream,
-                       g, a, fill.out_rgba, (int)n_col_blocks, (int)n_cols, make_int2(fill.cut[2], fill.cut[3]));
+    if (pipelined) {
+        hipLaunchKernelGGL(columns_fill_kernel<1>, dim3((unsigned)(n_col_blocks + n_fill)), dim3(waves * 64), 0, stream, g,
+                           a, fill.out_rgba, (int)n_col_blocks, (int)n_cols, make_int2(fill.cut[2], fill.cut[3]));
+    } else {
+        hipLaunchKernelGGL(columns_fill_kernel<2>, dim3((unsigned)(n_col_blocks + n_fill)), dim3(waves * 64), 0, stream, g,
+                           a, fill.out_rgba, (int)n_col_blocks, (int)n_cols, make_int2(fill.cut[2], fill.cut[3]));
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !a.trace_bg) return e;
     hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);

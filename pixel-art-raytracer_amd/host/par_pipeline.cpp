@@ -171,7 +171,8 @@ int main(int argc, char** argv) {
             scene_of(f, cur);
             PAR_OK_(s.ctx, par_update_aabbs_async(s.ctx, cur.data(), 0, prims, s.stream));
         }
-        const unsigned fl = all_flags | ((stamps_from >= 0 && f >= stamps_from && f < stamps_from + inflight) ? (1u << 29) : 0u);
+        const unsigned fl = all_flags | (inflight > 1 ? (unsigned)PAR_RENDER_PIPELINED : 0u) |
+                            ((stamps_from >= 0 && f >= stamps_from && f < stamps_from + inflight) ? (1u << 29) : 0u);
         PAR_OK_(s.ctx, par_render_device(s.ctx, s.stream, 0, H, &s.out, fl));
         return 0;
     };

@@ -159,7 +159,9 @@ int main(int argc, char** argv) {
 
     auto submit = [&](int f) -> int {
         Slot& s = slots[(size_t)f % slots.size()];
-        if (my1 > my0) PAR_OK_(s.ctx, par_render_device(s.ctx, s.stream, my0, my1, &s.out, 0));
+        if (my1 > my0) {
+            PAR_OK_(s.ctx, par_render_device(s.ctx, s.stream, my0, my1, &s.out, inflight > 1 ? PAR_RENDER_PIPELINED : 0u));
+        }
         // the frame's only exchange: its row blocks to rank 0, behind the render on the same stream
         NCCL_OK(ncclGather(s.block, s.gathered, block_px * sizeof(par_color), ncclUint8, 0, s.comm, s.stream));
         return 0;

@@ -14,7 +14,7 @@ import time
 import numpy as np
 import torch
 
-from . import Renderer, lib, plane_bytes
+from . import RENDER_PIPELINED, Renderer, lib, plane_bytes
 from .types import Outputs
 
 
@@ -123,6 +123,8 @@ class FramePipeline:
     def submit(self, i, flags=0):
         """Enqueue frame i on its slot's stream (asynchronous). Returns the slot."""
         s = self.slot(i)
+        if len(self.slots) > 1:
+            flags |= RENDER_PIPELINED  # several frames in flight: throughput before latency
         s.renderer.render_device(s.ptrs, rows=s.rows, flags=flags, stream=s.stream.cuda_stream)
         return s
 
