@@ -1629,8 +1629,9 @@ static int64_t column_blocks(const par_grid_dev& g, const par_render_args& a, in
 // full floor 330 against 346 us; the 480x320 graybox scene, 94 columns, 13.5 against 12.0 us: few columns need the
 // second wavefront for their walks even then.)
 static bool one_wave_per_column(const par_grid_dev& g, const par_render_args& a, int64_t column_bound) {
+    static const bool off = [] { const char* e = std::getenv("PAR_TUNE_NO_PIPELINED"); return e && e[0] == '1'; }();
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
-    return (a.flags & PAR_RENDER_PIPELINED) != 0 && std::min(column_bound, cols_in_range) >= 1024;
+    return !off && (a.flags & PAR_RENDER_PIPELINED) != 0 && std::min(column_bound, cols_in_range) >= 1024;
 }
 
 hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
