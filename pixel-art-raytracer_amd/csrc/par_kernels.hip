@@ -1000,7 +1000,9 @@ struct OwnTexel {
 
 // DBG: the debug / instrumentation flags of the frame are looked at (ablation bits 24-26, time stamps bit 29, ray
 // counting); the production kernels are compiled without them.
-template <bool GENERIC, bool DBG>
+// IDS: the scene may have a sprite-id table (looked at at run time); without one (the render launch knows) every
+// entity uses sprite 0 and the table arithmetic (two 32-bit multiplies per candidate entry) is compiled out.
+template <bool GENERIC, bool DBG, bool IDS = true>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
                                              const ColumnRegs& cr, uint64_t dup, const par_frame_dyn& dyn,
                                              int n_entries, int n_nb, int bx, int by, int own, int col, int row,
@@ -1033,7 +1035,7 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
             cur_bz = bz;
             hit_in_bin = false;
         };
-        const bool has_ids = a.sprite_ids != nullptr;
+        const bool has_ids = IDS && a.sprite_ids != nullptr;
         auto test = [&](const par_slot& rec, int e) {
             const int top = rec.py + rec.ey + rec.pz + rec.ez;
             // alt:310-317 (one predicate: no branch per condition)
@@ -1134,7 +1136,7 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         if (p_tex != pre_tex) {  // another entry won (or nothing was fetched ahead)
             ti = a.texinfo[p_tex];
             if (a.out.palidx) {
-                const int sid = p_tex / PAR_SPRITE_TEXELS;
+                const int sid = IDS ? p_tex / PAR_SPRITE_TEXELS : 0;
                 pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
             }
         }
@@ -1303,7 +1305,7 @@ __device__ __forceinline__ void render_column_generic(const par_grid_dev& g, con
 // (v_readlane). No LDS, no barrier, no loop over chunks: every wavefront of the launch is a handful of dependent
 // loads long, whatever its column looks like.
 // The item as two 16-byte words (par_item: {ci, visit, where, bins}, {entry}).
-template <bool DBG>
+template <bool DBG, bool IDS>
 __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, uint4 ib,
                                             int lane) {
     const uint32_t fl = DBG ? a.flags : 0u;
@@ -1355,7 +1357,7 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     OwnTexel pre;
     pre.tex = -1; pre.pal = 0; pre.depth = 0;
     pre.ti = par_texel{0.f, 0.f, 0.f, 0u};
-    if (!tile_mode && valid && !a.sprite_ids) {  // (with a sprite-id table the texel is not known yet)
+    if (!tile_mode && valid && !(IDS && a.sprite_ids)) {  // (with a sprite-id table the texel is not known yet)
         const int sprite_row = own_rec.py + own_rec.ey + own_rec.pz + own_rec.ez - (int)(int16_t)(H - row);  // alt:324-326
         pre.tex = sprite_row * PAR_SPRITE_W + (col - own_rec.px);                                            // alt:330-332
         pre.depth = a.sprites[0].depth[pre.tex];
@@ -1400,14 +1402,14 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
     // (a simple column's only entry sits in every lane: it is read as entry 0 whatever its index in the record was)
     const int own = tile_mode ? -1 : (simple ? 0 : (int)pass);
-    render_chunk<false, DBG>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, valid,
+    render_chunk<false, DBG, IDS>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, valid,
                              lane, nullptr, pre);
     asm volatile("" ::"v"(touched));  // (keeps the touch alive; nothing reads it)
 }
 
 // Wavefront `w` of `n_waves` (a multiple of PAR_ITEM_SHARDS): items w / shards, + n_waves / shards, ... of shard
 // w mod shards. The launch offers one wavefront per item of the host's bound, so the loop normally runs once.
-template <bool DBG>
+template <bool DBG, bool IDS>
 __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
     const int lane = (int)threadIdx.x & 63;
     const int shard = w & (PAR_ITEM_SHARDS - 1);
@@ -1420,7 +1422,7 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     stamp(g, DBG ? a.flags : 0u, 3, 1);
     for (int i = first; i < n;) {
         if (it[0] != PAR_ITEM_NONE) {
-            render_item<DBG>(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
+            render_item<DBG, IDS>(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
         }
         i += n_waves >> PAR_ITEM_SHARD_BITS;
         if (i < n) {
@@ -1430,13 +1432,13 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     }
 }
 
-template <bool DBG>
+template <bool DBG, bool IDS>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid_dev g, par_render_args a) {
     stamp(g, DBG ? a.flags : 0u, 3, 0);
     const unsigned long long core0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
     const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-    render_items<DBG>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
+    render_items<DBG, IDS>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
     stamp(g, DBG ? a.flags : 0u, 3, 7);
     if (DBG && g.stamps && (a.flags & (1u << 29)) && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
         // slot 5: the wavefront's life in shader-clock cycles (s_memtime), beside slots 0 / 7 in 100 MHz ticks
@@ -1475,7 +1477,7 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_
     const int b = (int)blockIdx.x;
     if (b < n_item_wgs) {
         const int w = __builtin_amdgcn_readfirstlane(b * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-        render_items<DBG>(g, a, w, n_item_wgs * PAR_WAVE_NW);
+        render_items<DBG, true>(g, a, w, n_item_wgs * PAR_WAVE_NW);
         return;
     }
     const int j = b - n_item_wgs;  // (workgroups of this kind exist only when some column may overflow)
@@ -1754,12 +1756,13 @@ static int64_t item_workgroups(int64_t item_bound) {
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
                              hipStream_t stream) {
     if (item_bound <= 0 || a.dense) return hipSuccess;
+    const dim3 grid((unsigned)item_workgroups(item_bound)), block(PAR_WAVE_NW * 64);
     if (a.flags & PAR_DEBUG_FLAGS) {
-        hipLaunchKernelGGL(render_items_kernel<true>, dim3((unsigned)item_workgroups(item_bound)), dim3(PAR_WAVE_NW * 64),
-                           0, stream, g, a);
-    } else {
-        hipLaunchKernelGGL(render_items_kernel<false>, dim3((unsigned)item_workgroups(item_bound)),
-                           dim3(PAR_WAVE_NW * 64), 0, stream, g, a);
+        hipLaunchKernelGGL((render_items_kernel<true, true>), grid, block, 0, stream, g, a);
+    } else if (a.sprite_ids) {
+        hipLaunchKernelGGL((render_items_kernel<false, true>), grid, block, 0, stream, g, a);
+    } else {  // every entity uses sprite 0 (the reference's own scenes)
+        hipLaunchKernelGGL((render_items_kernel<false, false>), grid, block, 0, stream, g, a);
     }
     return hipGetLastError();
 }

@@ -6,7 +6,7 @@
 // shows the frame rate without an interpreter in the submit path.
 //
 //   par_pipeline [--size S] [--prims N] [--frames F] [--inflight K] [--threads T] [--moving] [--check] [--flags X]
-//                [--stamps F0]
+//                [--stamps F0] [--block K]
 //
 // --flags X: render flags for every frame (the timing-experiment bits of par_raytracer.h; the output is then wrong).
 // --stamps F0 (with PAR_DEBUG_STAMPS=1 in the environment): the K frames from F0 on note the GPU's 100 MHz clock at
@@ -63,6 +63,7 @@ static double now_s() {
 }
 
 int main(int argc, char** argv) {
+    int block = 0;
     int size = 4096, prims = 1024, frames = 2000, inflight = 4;
     bool moving = false, check = false;
     int stamps_from = -1, threads = 1;
@@ -79,6 +80,7 @@ int main(int argc, char** argv) {
         else if (a == "--check") check = true;
         else if (a == "--stamps") next(stamps_from);
         else if (a == "--threads") next(threads);
+        else if (a == "--block") next(block);
         else if (a == "--scene") { if (i + 1 < argc) scene = argv[++i]; }
         else if (a == "--flags") { int v = 0; next(v); all_flags = (unsigned)v; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
@@ -179,6 +181,41 @@ int main(int argc, char** argv) {
     const int warm = std::min(frames, 200);
     for (int f = 0; f < warm; f++) if (submit(f)) return 1;
     HIP_OK(hipDeviceSynchronize());
+    if (block > 0) {
+        // --block K: blocks of K frames, each started on an idle device and waited for (what a bench step loop of
+        // K steps between two synchronisations sees), with an event behind every frame: when did frame i of the
+        // block complete? Median over 25 blocks.
+        const int n_blocks = 25;
+        std::vector<hipEvent_t> ev((size_t)block + 1);
+        for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+        std::vector<std::vector<float>> done((size_t)block, std::vector<float>());
+        std::vector<double> wall;
+        for (int b = 0; b < n_blocks; b++) {
+            HIP_OK(hipDeviceSynchronize());
+            const double tb = now_s();
+            HIP_OK(hipEventRecord(ev[0], slots[0].stream));
+            for (int f = 0; f < block; f++) {
+                if (submit(f)) return 1;
+                HIP_OK(hipEventRecord(ev[(size_t)f + 1], slots[(size_t)f % slots.size()].stream));
+            }
+            HIP_OK(hipDeviceSynchronize());
+            wall.push_back(1e6 * (now_s() - tb));
+            for (int f = 0; f < block; f++) {
+                float ms = 0.f;
+                HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[(size_t)f + 1]));
+                done[(size_t)f].push_back(ms * 1e3f);
+            }
+        }
+        std::sort(wall.begin(), wall.end());
+        std::printf("block of %d frames, %d in flight: median wall %.1f us = %.2f us per frame\ncompleted at (us):", block,
+                    inflight, wall[wall.size() / 2], wall[wall.size() / 2] / block);
+        for (int f = 0; f < block; f++) {
+            std::sort(done[(size_t)f].begin(), done[(size_t)f].end());
+            std::printf(" %.0f", done[(size_t)f][done[(size_t)f].size() / 2]);
+        }
+        std::printf("\n");
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
     const double t0 = now_s();
     if (threads <= 1 || moving) {
         for (int f = 0; f < frames; f++) if (submit(f)) return 1;
