@@ -1006,7 +1006,8 @@ template <bool GENERIC, bool DBG, bool IDS = true>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
                                              const ColumnRegs& cr, uint64_t dup, const par_frame_dyn& dyn,
                                              int n_entries, int n_nb, int bx, int by, int own, int col, int row,
-                                             int row_lo, int row_hi, bool valid, int lane, WaveScratch* ws,
+                                             int row_lo, int row_hi, int col_lo, int col_hi, bool valid, int lane,
+                                             WaveScratch* ws,
                                              const OwnTexel& pre = OwnTexel{-1, 0, 0, par_texel{0.f, 0.f, 0.f, 0u}}) {
     const int W = a.W, H = a.H;
     const uint32_t fl = DBG ? a.flags : 0u;
@@ -1066,16 +1067,18 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
             // The record's entries as one flat list, front to back. Lane e holds entry e: ONE vector comparison says
             // which entries can cover a pixel of this chunk at all (not a repeat of an earlier entry's entity: the
             // same AABB in another bin gives the same depth, so it can neither improve `closest`, strict compare
-            // alt:344, nor be the first to cover; and its rows meet the chunk's rows [row_lo, row_hi]); only those
+            // alt:344, nor be the first to cover; and its rectangle meets the chunk's box, rows [row_lo, row_hi] x
+            // columns [col_lo, col_hi]); only those
             // are visited. The bins of the entries skipped are occupied bins without a hit: they leave `adjacent`
             // alone (only an EMPTY bin resets it, alt:298-300), so all the visit needs to know of them is whether
             // an empty bin lies between two visited ones: `gaps` counts the empty stretches up to an entry's bin.
             const int16_t my_px = (int16_t)(cr.ent.x & 0xFFFF), my_py = (int16_t)(cr.ent.x >> 16);
             const int16_t my_pz = (int16_t)(cr.ent.y & 0xFFFF);
             const int16_t my_ey = (int16_t)(cr.ent.z & 0xFFFF), my_ez = (int16_t)(cr.ent.z >> 16);
-            (void)my_px;
+            const int16_t my_ex = (int16_t)(cr.ent.y >> 16);
             const int my_top_row = H - (my_py + my_ey + my_pz + my_ez), my_end_row = H - (my_py + my_pz);
-            const bool mine = lane < n_entries && !((dup >> lane) & 1) && !(row_hi < my_top_row || row_lo >= my_end_row);
+            const bool mine = lane < n_entries && !((dup >> lane) & 1) && !(row_hi < my_top_row || row_lo >= my_end_row) &&
+                              !(col_hi < my_px || col_lo >= my_px + my_ex);
             uint64_t todo = __ballot(mine);
             const int prev_bz = __shfl_up(cr.ebz, 1);
             const uint64_t gap_mask = __ballot(lane > 0 && lane < n_entries && cr.ebz != prev_bz && cr.ebz != prev_bz + 1);
@@ -1293,7 +1296,7 @@ __device__ __forceinline__ void render_column_generic(const par_grid_dev& g, con
         const int p_first = c * 64, p_last = min(p_first + 63, area - 1);
         const int row_lo = ry0 + ((rw == 1) ? p_first : (int)__umulhi((uint32_t)p_first, magic_w));
         const int row_hi = ry0 + ((rw == 1) ? p_last : (int)__umulhi((uint32_t)p_last, magic_w));
-        render_chunk<true, true>(g, a, rec_, cr, 0, dyn, 0, 0, bx, by, -1, col, row, row_lo, row_hi, pidx < area, lane,
+        render_chunk<true, true>(g, a, rec_, cr, 0, dyn, 0, 0, bx, by, -1, col, row, row_lo, row_hi, c0, c0 + rw - 1, pidx < area, lane,
                            ws + wave);
     }
 }
@@ -1342,18 +1345,44 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const int area = rw * rh;
     const int p_first = chunk * 64, p_last = min(p_first + 63, area - 1);
     if (p_first >= area) return;
-    // floor(p / rw) through a float reciprocal: p < 2^15 and rw <= PAR_MAX_BIN, so (p + 0.5) / rw is at least
-    // 0.5 / PAR_MAX_BIN away from every integer, far more than the rounding of the three float operations
-    // (an integer division by a run-time value costs some forty instructions per wavefront)
-    const float inv_rw = __builtin_amdgcn_rcpf((float)rw);
-    auto div_rw = [&](int p) { return (int)(((float)p + 0.5f) * inv_rw); };
+    // The rectangle is visited in vertical STRIPS of at most 20 pixels' width (a sprite's), row by row within a
+    // strip: a 64-pixel chunk is then a few rows of one strip instead of one or two rows across the whole width,
+    // and fewer entries' rectangles meet it (a full floor: 2.4 instead of 4.4 candidate entries per chunk). An
+    // entry pass has one strip (its rectangle is no wider than a sprite).
+    // floor(p / d) through a float reciprocal: p < 2^15 and d <= PAR_MAX_BIN^2 = 25 600, so (p + 0.5) / d is at
+    // least 0.5 / 25 600 away from every integer, far more than the rounding of the three float operations on a
+    // quotient below 2^15 / d (an integer division by a run-time value costs some forty instructions per wavefront)
+    const int n_strips = (rw + PAR_SPRITE_W - 1) / PAR_SPRITE_W;
+    const int sw = (rw + n_strips - 1) / n_strips, lw = rw - (n_strips - 1) * sw;  // strip width, the last strip's
     const int pidx = p_first + lane;
-    const int pyy = div_rw(pidx);
-    const int col = rx0 + (pidx - pyy * rw), row = ry0 + pyy;
     const bool valid = pidx < area;
-    // the chunk's first and last row (wave-uniform)
-    const int row_lo = ry0 + __builtin_amdgcn_readfirstlane(div_rw(p_first));
-    const int row_hi = ry0 + __builtin_amdgcn_readfirstlane(div_rw(p_last));
+    int col, row, strip = 0;
+    {
+        int q = pidx, w_l = rw;
+        float inv_w = __builtin_amdgcn_rcpf((float)sw);
+        if (n_strips > 1) {  // (wave-uniform)
+            const int strip_px = sw * rh;
+            strip = min((int)(((float)pidx + 0.5f) * __builtin_amdgcn_rcpf((float)strip_px)), n_strips - 1);
+            q = pidx - strip * strip_px;
+            const bool last = strip == n_strips - 1;
+            w_l = last ? lw : sw;
+            inv_w = last ? __builtin_amdgcn_rcpf((float)lw) : inv_w;
+        }
+        const int pyy = (int)(((float)q + 0.5f) * inv_w);
+        col = rx0 + strip * sw + (q - pyy * w_l);
+        row = ry0 + pyy;
+    }
+    // the chunk's box (wave-uniform): the rows and columns of its first and last pixel when both lie in one strip,
+    // the whole rectangle otherwise
+    const int last_lane = p_last - p_first;
+    const int strip_a = __builtin_amdgcn_readfirstlane(strip), strip_b = __builtin_amdgcn_readlane(strip, last_lane);
+    int row_lo = ry0, row_hi = ry0 + rh - 1, col_lo = rx0, col_hi = rx0 + rw - 1;
+    if (strip_a == strip_b) {
+        row_lo = __builtin_amdgcn_readfirstlane(row);
+        row_hi = __builtin_amdgcn_readlane(row, last_lane);
+        col_lo = rx0 + strip_a * sw;
+        col_hi = col_lo + (strip_a == n_strips - 1 ? lw : sw) - 1;
+    }
     OwnTexel pre;
     pre.tex = -1; pre.pal = 0; pre.depth = 0;
     pre.ti = par_texel{0.f, 0.f, 0.f, 0u};
@@ -1402,7 +1431,7 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
     // (a simple column's only entry sits in every lane: it is read as entry 0 whatever its index in the record was)
     const int own = tile_mode ? -1 : (simple ? 0 : (int)pass);
-    render_chunk<false, DBG, IDS>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, valid,
+    render_chunk<false, DBG, IDS>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, col_lo, col_hi, valid,
                              lane, nullptr, pre);
     asm volatile("" ::"v"(touched));  // (keeps the touch alive; nothing reads it)
 }
