@@ -157,7 +157,9 @@ int par_read_grid(par_context* ctx, int32_t* count, int32_t* map, par_aabb* bins
  * (tests/golden/ref_units.npz holds the reference's own answers). kind 0: AABB::intersect, alt:40-83 — in_a =
  * par_aabb[n], in_b = n x {float inv_x, inv_y, inv_z; int16 origin x, y, z; int16 pad} (`Ray`, alt:30-33), out =
  * uint8_t[n]. kind 1: Color::operator*(float), spr:8-16 — in_a = n x {float r, g, b, a, v}, out = n x uint8_t[4].
- * kind 2: Vector::normalize, spr:28-35 — in_a = n x float[3], out = n x float[3]. */
+ * kind 2: Vector::normalize, spr:28-35 — in_a = n x float[3], out = n x float[3]. kinds 3 and 4: kind 0's test as the
+ * render kernel runs it on the records of a shadow walk (planes as floats, packed arithmetic; 3: hardware min/max
+ * where the inverse direction is finite, 4: the reference's compare-selects throughout), same arguments. */
 int par_debug_units(int device, int kind, const void* in_a, const void* in_b, int n, void* out);
 
 /* --- host-side scene helpers (C++ host code, no GPU needed) ---------------------------------------------------- */

@@ -124,11 +124,12 @@ def lib():
 def debug_units(kind, in_a, in_b=None, device=0):
     """The reference's arithmetic units as the device kernels compute them (par_debug_units). kind 0: intersect
     (AABB[n], RAY[n]) -> uint8[n]; 1: color scale (float32[n, 5]) -> uint8[n, 4]; 2: normalize (float32[n, 3]) ->
-    float32[n, 3]."""
+    float32[n, 3]; 3, 4: intersect as the render kernel runs it on a shadow walk's records (floats, packed; 3: hardware
+    min / max where the inverse direction is finite, 4: the reference's compare-selects throughout)."""
     a = np.ascontiguousarray(in_a)
     b = None if in_b is None else np.ascontiguousarray(in_b)
     n = len(a)
-    out = np.zeros(n, dtype=np.uint8) if kind == 0 else (np.zeros((n, 4), dtype=np.uint8) if kind == 1
+    out = np.zeros(n, dtype=np.uint8) if kind in (0, 3, 4) else (np.zeros((n, 4), dtype=np.uint8) if kind == 1
                                                          else np.zeros((n, 3), dtype=np.float32))
     rc = lib().par_debug_units(device, kind, ptr(a), ptr(b), n, ptr(out))
     if rc != PAR_OK:

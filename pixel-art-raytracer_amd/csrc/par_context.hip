@@ -1093,16 +1093,17 @@ static int par_read_grid_impl(par_context* ctx, int32_t* count, int32_t* map, pa
 // Test hook: the reference's three arithmetic units as the DEVICE computes them (slab_hit, color_scale,
 // normalize_l1_and_inverse of par_kernels.hip) on host vectors. See par_raytracer.h.
 static int par_debug_units_impl(int device, int kind, const void* in_a, const void* in_b, int n, void* out) {
-    if (kind < 0 || kind > 2 || n < 0 || !in_a || !out || (kind == 0 && !in_b)) return PAR_ERR_INVALID_ARG;
+    const bool slab = kind == 0 || kind == 3 || kind == 4;  // (3, 4: the slab test on a walk record, par_kernels.hip)
+    if (kind < 0 || kind > 4 || n < 0 || !in_a || !out || (slab && !in_b)) return PAR_ERR_INVALID_ARG;
     par_context* ctx = nullptr;  // (PAR_HIP reports through it)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return PAR_ERR_NO_DEVICE;
     if (device < 0) device = 0;
     if (device >= ndev) return PAR_ERR_INVALID_ARG;
     PAR_HIP(hipSetDevice(device));
-    const size_t a_bytes = (size_t)n * (kind == 0 ? sizeof(par_aabb) : (kind == 1 ? 5 : 3) * sizeof(float));
-    const size_t b_bytes = kind == 0 ? (size_t)n * 20 : 0;
-    const size_t o_bytes = (size_t)n * (kind == 0 ? 1 : (kind == 1 ? 4 : 12));
+    const size_t a_bytes = (size_t)n * (slab ? sizeof(par_aabb) : (kind == 1 ? 5 : 3) * sizeof(float));
+    const size_t b_bytes = slab ? (size_t)n * 20 : 0;
+    const size_t o_bytes = (size_t)n * (slab ? 1 : (kind == 1 ? 4 : 12));
     void *da = nullptr, *db = nullptr, *dout = nullptr;
     hipError_t e = hipMalloc(&da, std::max<size_t>(a_bytes, 16));
     if (e == hipSuccess) e = hipMalloc(&db, std::max<size_t>(b_bytes, 16));

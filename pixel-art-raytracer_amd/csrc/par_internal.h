@@ -39,6 +39,16 @@ struct par_texel {
 };
 static_assert(sizeof(par_texel) == 16, "texel record must stay 16 bytes");
 
+// An occluder record of a shadow walk as the render kernel's slab test wants it: the box's two planes per axis as
+// floats (the coordinates are 16-bit integers and sums of two, exact in a float, and so is their difference to a
+// ray origin: (float)(p - o) == (float)p - (float)o), a pair per axis so that one packed instruction handles both.
+struct par_walkrec {
+    float x_lo, x_hi, y_lo, y_hi, z_lo, z_hi;  // p, p + e (alt:44-46, 59-60, 71-72)
+    int32_t entity;
+    int32_t pad_;
+};
+static_assert(sizeof(par_walkrec) == 32, "walk record layout");
+
 struct par_colrec_nb {
     int16_t bz;          // bin_z of an occupied bin of the column, ascending
     uint8_t off, cnt;    // its records: entries[off, off+cnt)
@@ -55,7 +65,7 @@ struct par_colrec {
     par_colrec_nb nb[PAR_COL_NB];
     int16_t ebz[PAR_COL_ENT];  // bin_z of each entry (the primary pass walks the entries as one flat list)
     par_slot entries[PAR_COL_ENT];
-    par_slot walk[PAR_COL_WALK];
+    par_walkrec walk[PAR_COL_WALK];
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");

@@ -312,6 +312,36 @@ __device__ __forceinline__ bool slab_hit(const par_slot& r, int ox, int oy, int 
     return tmax >= tmin;
 }
 
+// The same test on a walk record (par_walkrec: the planes as floats, lo / hi pairs): the differences to the origin
+// are exact in both forms, so every product is the one above; two values per packed instruction.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ par_walkrec walkrec_of(const par_slot& r) {
+    par_walkrec w;
+    w.x_lo = (float)r.px; w.x_hi = (float)(r.px + r.ex);
+    w.y_lo = (float)r.py; w.y_hi = (float)(r.py + r.ey);
+    w.z_lo = (float)r.pz; w.z_hi = (float)(r.pz + r.ez);
+    w.entity = r.entity;
+    w.pad_ = 0;
+    return w;
+}
+template <bool FINITE>
+__device__ __forceinline__ bool slab_hit_rec(const v2f& rx, const v2f& ry, const v2f& rz, float fox, float foy,
+                                             float foz, float ix, float iy, float iz) {
+    const v2f tx = (rx - fox) * ix, ty = (ry - foy) * iy, tz = (rz - foz) * iz;
+    if (FINITE) {
+        const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fminf(tz.x, tz.y));
+        const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fmaxf(tz.x, tz.y));
+        return tmax >= tmin;
+    }
+    float tmin = std_min(tx.x, tx.y);
+    float tmax = std_max(tx.x, tx.y);
+    tmin = std_max(tmin, std_min(ty.x, ty.y));
+    tmax = std_min(tmax, std_max(ty.x, ty.y));
+    tmin = std_max(tmin, std_min(tz.x, tz.y));
+    tmax = std_min(tmax, std_max(tz.x, tz.y));
+    return tmax >= tmin;
+}
+
 // Color::operator*, spr:8-16: truncating per-channel scale, alpha passed through. `c` is RGBA little-endian.
 __device__ __forceinline__ uint32_t color_scale(uint32_t c, float v) {
     const uint32_t r = (uint32_t)(uint8_t)((float)(c & 0xFF) * v);
@@ -597,8 +627,8 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
                     sm.nb[i].wcnt = -1;
                 }
             } else {
-                par_slot* dst = g.colrec[ci].walk + walk_lo + n_walk;
-                for (int r = lane; r < n_rec; r += 64) dst[r] = sm.stage[r];
+                par_walkrec* dst = g.colrec[ci].walk + walk_lo + n_walk;
+                for (int r = lane; r < n_rec; r += 64) dst[r] = walkrec_of(sm.stage[r]);
                 if (lane == 0) {
                     sm.nb[i].woff = (int16_t)(walk_lo + n_walk);
                     sm.nb[i].wcnt = (int16_t)n_rec;
@@ -1169,17 +1199,29 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
             }
         }
         if (wcnt >= 0) {
-            // four records per step: their loads are in flight together
-            const par_slot* wl = rec_.walk + woff;
+            // two records (four 16-byte loads) per step: their loads are in flight together
+            const char* walk_base = reinterpret_cast<const char*>(rec_.walk);  // (wave-uniform; 32-bit lane offsets)
+            const float fox = (float)ox, foy = (float)oy, foz = (float)oz;
             auto test_list = [&](auto finite) {
-                for (int r0 = 0; r0 < wcnt && lit; r0 += 4) {
-                    par_slot w[4];
+                for (int r0 = 0; r0 < wcnt && lit; r0 += 2) {
+                    uint4 wa[2], wb[2];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) w[u] = wl[min(r0 + u, wcnt - 1)];
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t off = (uint32_t)(woff + min(r0 + u, wcnt - 1)) * (uint32_t)sizeof(par_walkrec);
+                        const uint4* q = reinterpret_cast<const uint4*>(walk_base + off);
+                        wa[u] = q[0];
+                        wb[u] = q[1];
+                    }
+                    // (all four loads are issued before the first record is looked at: the compiler otherwise sinks
+                    // a record's planes below the comparison of its entity, a second round trip)
+                    asm volatile("" ::"v"(wa[0].x), "v"(wa[1].x), "v"(wb[0].x), "v"(wb[1].x));
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (r0 + u < wcnt && w[u].entity != p_entity &&
-                            slab_hit<decltype(finite)::value>(w[u], ox, oy, oz, inv_x, inv_y, inv_z)) {  // alt:484-491
+                    for (int u = 0; u < 2; u++) {
+                        const v2f rx = {__uint_as_float(wa[u].x), __uint_as_float(wa[u].y)};
+                        const v2f ry = {__uint_as_float(wa[u].z), __uint_as_float(wa[u].w)};
+                        const v2f rz = {__uint_as_float(wb[u].x), __uint_as_float(wb[u].y)};
+                        if (r0 + u < wcnt && (int)wb[u].z != p_entity &&
+                            slab_hit_rec<decltype(finite)::value>(rx, ry, rz, fox, foy, foz, inv_x, inv_y, inv_z)) {  // alt:484-491
                             lit = false;
                         }
                     }
@@ -1519,7 +1561,7 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_
 
 // Test hook (par_debug_units): the device functions of the reference's three arithmetic units on caller-supplied
 // vectors, one element per thread. kind 0: AABB::intersect alt:40-83 (a: par_aabb, b: {float inv[3]; int16 origin[3]}
-// -> u8 hit); 1: Color::operator* spr:8-16 (a: float r, g, b, a, v -> u8[4]); 2: Vector::normalize spr:28-35
+// -> u8 hit; 3, 4: the same on a walk record, as the render kernel tests it); 1: Color::operator* spr:8-16 (a: float r, g, b, a, v -> u8[4]); 2: Vector::normalize spr:28-35
 // (a: float[3] -> float[3]).
 struct unit_ray {
     float inv_x, inv_y, inv_z;
@@ -1536,6 +1578,23 @@ __global__ __launch_bounds__(256) void units_kernel(int kind, const void* in_a, 
         rec.ex = box.ex; rec.ey = box.ey; rec.ez = box.ez;
         rec.entity = 0;
         static_cast<uint8_t*>(out)[i] = slab_hit(rec, ray.ox, ray.oy, ray.oz, ray.inv_x, ray.inv_y, ray.inv_z) ? 1 : 0;
+    } else if (kind == 3 || kind == 4) {
+        // the same test as the render kernel runs it: on a walk record, through the hardware min / max when the
+        // inverse direction is finite (kind 3; the kernel's choice, made per element here) or never (kind 4)
+        const par_aabb box = static_cast<const par_aabb*>(in_a)[i];
+        const unit_ray ray = static_cast<const unit_ray*>(in_b)[i];
+        par_slot rec;
+        rec.px = box.px; rec.py = box.py; rec.pz = box.pz;
+        rec.ex = box.ex; rec.ey = box.ey; rec.ez = box.ez;
+        rec.entity = 0;
+        const par_walkrec w = walkrec_of(rec);
+        const v2f rx = {w.x_lo, w.x_hi}, ry = {w.y_lo, w.y_hi}, rz = {w.z_lo, w.z_hi};
+        const float fox = (float)ray.ox, foy = (float)ray.oy, foz = (float)ray.oz;
+        const bool finite = kind == 3 && __builtin_isfinite(ray.inv_x) && __builtin_isfinite(ray.inv_y) &&
+                            __builtin_isfinite(ray.inv_z);
+        const bool hit = finite ? slab_hit_rec<true>(rx, ry, rz, fox, foy, foz, ray.inv_x, ray.inv_y, ray.inv_z)
+                                : slab_hit_rec<false>(rx, ry, rz, fox, foy, foz, ray.inv_x, ray.inv_y, ray.inv_z);
+        static_cast<uint8_t*>(out)[i] = hit ? 1 : 0;
     } else if (kind == 1) {
         const float* v = static_cast<const float*>(in_a) + (size_t)i * 5;
         const uint32_t c = (uint32_t)(uint8_t)v[0] | ((uint32_t)(uint8_t)v[1] << 8) | ((uint32_t)(uint8_t)v[2] << 16) |

@@ -176,6 +176,10 @@ def test_device_units_equal_the_reference(par, T):
     assert np.isnan(rays["inv_x"]).any() and np.isinf(rays["inv_y"]).any()
     hit = par.debug_units(0, boxes, rays)
     assert np.array_equal(hit, z["hit"])
+    # ... and as the render kernel tests a shadow walk's records (float planes, packed arithmetic; hardware min / max
+    # where the inverse direction is finite, the reference's compare-selects otherwise or throughout)
+    assert np.array_equal(par.debug_units(3, boxes, rays), z["hit"])
+    assert np.array_equal(par.debug_units(4, boxes, rays), z["hit"])
     cs = par.debug_units(1, z["cs_in"].astype(np.float32))
     assert np.array_equal(cs, z["cs_out"])
     nv = par.debug_units(2, z["nv"].astype(np.float32))
