@@ -1394,8 +1394,9 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     // floor(p / d) through a float reciprocal: p < 2^15 and d <= PAR_MAX_BIN^2 = 25 600, so (p + 0.5) / d is at
     // least 0.5 / 25 600 away from every integer, far more than the rounding of the three float operations on a
     // quotient below 2^15 / d (an integer division by a run-time value costs some forty instructions per wavefront)
-    const int n_strips = (rw + PAR_SPRITE_W - 1) / PAR_SPRITE_W;
-    const int sw = (rw + n_strips - 1) / n_strips, lw = rw - (n_strips - 1) * sw;  // strip width, the last strip's
+    const int n_strips = (int)(((uint32_t)(rw + PAR_SPRITE_W - 1) * 3277u) >> 16);  // / 20 for values < 2^13 (PAR_SPRITE_W)
+    static_assert(PAR_SPRITE_W == 20, "the strip count divides by the sprite width through a multiplier");
+    const int sw = min(rw, PAR_SPRITE_W), lw = rw - (n_strips - 1) * sw;  // strip width, the last strip's
     const int pidx = p_first + lane;
     const bool valid = pidx < area;
     int col, row, strip = 0;
@@ -1405,13 +1406,13 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
         if (n_strips > 1) {  // (wave-uniform)
             const int strip_px = sw * rh;
             strip = min((int)(((float)pidx + 0.5f) * __builtin_amdgcn_rcpf((float)strip_px)), n_strips - 1);
-            q = pidx - strip * strip_px;
+            q = pidx - __mul24(strip, strip_px);  // (all of these products are below 2^24: full-rate multiplies)
             const bool last = strip == n_strips - 1;
             w_l = last ? lw : sw;
             inv_w = last ? __builtin_amdgcn_rcpf((float)lw) : inv_w;
         }
         const int pyy = (int)(((float)q + 0.5f) * inv_w);
-        col = rx0 + strip * sw + (q - pyy * w_l);
+        col = rx0 + __mul24(strip, sw) + (q - __mul24(pyy, w_l));
         row = ry0 + pyy;
     }
     // the chunk's box (wave-uniform): the rows and columns of its first and last pixel when both lie in one strip,

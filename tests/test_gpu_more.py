@@ -251,7 +251,7 @@ with par.Renderer(params) as r:
 print("generic ok")
 ''' % root
     env = dict(os.environ, PAR_FORCE_GENERIC="1")
-    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "generic ok" in p.stdout, p.stderr[-3000:]
 
 
@@ -458,7 +458,7 @@ def test_bench_multi_rank_control_flow(world):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", str(world), "--steps", "12", "--warmup", "3", "--blocks", "3", "--backend", "gloo", "--share-gpu",
            "--size", "1000" if world == 3 else "1024", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Render N frames of one workload (for rocprofv3 --kernel-trace --stats / --pmc runs on the GPU box).
-usage: frames.py [synthetic|floor|graybox|trace_bg] [frames]"""
+usage: frames.py [synthetic|floor|graybox|trace_bg] [frames] [extra render flags, e.g. the ablation bits 24-28]"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +10,7 @@ T = par.types
 what = sys.argv[1] if len(sys.argv) > 1 else "synthetic"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 flags = 0
+extra = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
 if what in ("synthetic", "trace_bg"):
     W = H = L = 4096
     p = T.default_params(W, H, L)
@@ -31,6 +32,6 @@ pal = torch.zeros(W * H, dtype=torch.uint8, device="cuda")
 ptrs = {"fb": fb.data_ptr(), "palidx": pal.data_ptr()}
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(n):
-    r.render_device(ptrs, stream=s, flags=flags)
+    r.render_device(ptrs, stream=s, flags=flags | extra)
 torch.cuda.synchronize()
 print("done", what, n, "frames; occupied columns", r.stats().occupied_columns)

@@ -1,14 +1,15 @@
 #!/bin/bash
-# GPU box: SQ counters per kernel (one frame at a time), several --pmc passes. usage: tools/pmc_kernels.sh <tag> [synthetic|floor|graybox]
+# GPU box: SQ counters per kernel (one frame at a time), several --pmc passes. usage: tools/pmc_kernels.sh <tag> [synthetic|floor|graybox] [extra render flags]  (PMC_SETS=valu: the first pass only)
 set -e
-tag=${1:-x}; what=${2:-synthetic}
+tag=${1:-x}; what=${2:-synthetic}; xflags=${3:-0}; sets=${PMC_SETS:-all}
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_LDS SQ_WAIT_ANY"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o pmc -- python3 tools/frames.py $what 30 > $out/p$i.log 2> $out/p$i.err || echo "pass $i failed: $set" >> $out/failed.txt
+  if [ "$sets" = valu ] && [ $i -gt 1 ]; then break; fi
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/p$i -o pmc -- python3 tools/frames.py $what 30 $xflags > $out/p$i.log 2> $out/p$i.err || echo "pass $i failed: $set" >> $out/failed.txt
 done
 python3 - <<PY
 import csv, glob, json, statistics, collections
