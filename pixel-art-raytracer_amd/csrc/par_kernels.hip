@@ -23,6 +23,7 @@
 // wins). With that every float the reference computes is reproduced bit for bit.
 #include "par_internal.h"
 #include "par_fastdiv.h"
+#include "par_strips.h"
 
 #include <limits.h>
 
@@ -1387,34 +1388,16 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const int area = rw * rh;
     const int p_first = chunk * 64, p_last = min(p_first + 63, area - 1);
     if (p_first >= area) return;
-    // The rectangle is visited in vertical STRIPS of at most 20 pixels' width (a sprite's), row by row within a
-    // strip: a 64-pixel chunk is then a few rows of one strip instead of one or two rows across the whole width,
-    // and fewer entries' rectangles meet it (a full floor: 2.4 instead of 4.4 candidate entries per chunk). An
-    // entry pass has one strip (its rectangle is no wider than a sprite).
-    // floor(p / d) through a float reciprocal: p < 2^15 and d <= PAR_MAX_BIN^2 = 25 600, so (p + 0.5) / d is at
-    // least 0.5 / 25 600 away from every integer, far more than the rounding of the three float operations on a
-    // quotient below 2^15 / d (an integer division by a run-time value costs some forty instructions per wavefront)
-    const int n_strips = (int)(((uint32_t)(rw + PAR_SPRITE_W - 1) * 3277u) >> 16);  // / 20 for values < 2^13 (PAR_SPRITE_W)
-    static_assert(PAR_SPRITE_W == 20, "the strip count divides by the sprite width through a multiplier");
-    const int sw = min(rw, PAR_SPRITE_W), lw = rw - (n_strips - 1) * sw;  // strip width, the last strip's
+    // the rectangle is visited in vertical strips of a sprite's width, row by row within a strip (par_strips.h)
+    static_assert(PAR_SPRITE_W == PAR_STRIP_W && PAR_MAX_BIN <= PAR_STRIP_MAX_SIDE, "par_strips.h is written for these");
+    const par_strips st = par_strips_of(rw);
+    const int n_strips = st.n_strips, sw = st.sw, lw = st.lw;
     const int pidx = p_first + lane;
     const bool valid = pidx < area;
-    int col, row, strip = 0;
-    {
-        int q = pidx, w_l = rw;
-        float inv_w = __builtin_amdgcn_rcpf((float)sw);
-        if (n_strips > 1) {  // (wave-uniform)
-            const int strip_px = sw * rh;
-            strip = min((int)(((float)pidx + 0.5f) * __builtin_amdgcn_rcpf((float)strip_px)), n_strips - 1);
-            q = pidx - __mul24(strip, strip_px);  // (all of these products are below 2^24: full-rate multiplies)
-            const bool last = strip == n_strips - 1;
-            w_l = last ? lw : sw;
-            inv_w = last ? __builtin_amdgcn_rcpf((float)lw) : inv_w;
-        }
-        const int pyy = (int)(((float)q + 0.5f) * inv_w);
-        col = rx0 + __mul24(strip, sw) + (q - __mul24(pyy, w_l));
-        row = ry0 + pyy;
-    }
+    int col, row, strip;
+    par_strip_pixel(st, rh, pidx, strip, col, row);
+    col += rx0;
+    row += ry0;
     // the chunk's box (wave-uniform): the rows and columns of its first and last pixel when both lie in one strip,
     // the whole rectangle otherwise
     const int last_lane = p_last - p_first;

@@ -145,6 +145,29 @@ def test_other_bin_sizes_and_palettes(par, oracle, sprite, T):
             assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"bin {bin_size}")
 
 
+def test_tile_passes_in_strips_wide_and_clipped_bins(par, oracle, sprite, T):
+    """Bins wider than two sprites and views that are no multiple of the bin, end to end: a render work item visits
+    its rectangle in strips of a sprite's width (csrc/par_strips.h; the arithmetic itself is checked for every
+    rectangle shape by test_strip_order_visits_every_pixel_once), and a view-clipped tile can have any width — 21
+    pixels (strips of 20 + 1), 1 pixel, 20. A floor plus scattered boxes of every extent; every plane against the
+    oracle, default mode and every ray traced."""
+    for bin_size, (w, h, l) in [(160, (500, 360, 360)), (100, (421, 300, 300)), (60, (241, 200, 200)),
+                                (120, (380, 250, 250))]:
+        params = T.default_params(w, h, l, bin_size)
+        rows = [(i * 20, 0, j * 20, 20, 20, 20) for i in range((w + 19) // 20) for j in range(l // 20)]
+        rng = np.random.default_rng(bin_size)
+        rows += [(int(rng.integers(0, w - 20)), int(rng.integers(20, 120)), int(rng.integers(0, l - 20)),
+                  int(rng.integers(1, 21)), int(rng.integers(1, 21)), int(rng.integers(1, 21))) for _ in range(150)]
+        aabbs = T.make_aabbs(rows)
+        light = T.make_light(w // 2 + 33, h // 2, l // 4)
+        exp = oracle.render(params, aabbs, sprite, light, nthreads=8)
+        with par.Renderer(params) as r:
+            r.set_scene(aabbs, sprite, light)
+            assert_planes_equal(r.render(ALL), exp, ALL, f"bin {bin_size} every ray")
+            fast = r.render(("fb", "palidx", "brightness", "gbuf"))
+            assert_planes_equal(fast, exp, ("fb", "palidx", "brightness", "gbuf"), f"bin {bin_size}")
+
+
 def test_full_size_headline_frame(par, oracle, sprite, T):
     """BASELINE's headline configuration itself: 4096x4096, 1024 primitives — bit-exact against the oracle (rows
     split over the host cores), plus the properties that do not depend on the oracle: the default (background rays

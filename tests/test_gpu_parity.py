@@ -200,3 +200,19 @@ def test_short_division_sequences_are_exact(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count(": 0 mismatches") == 2, p.stdout
+
+
+def test_strip_order_visits_every_pixel_once(tmp_path):
+    """A render work item visits its rectangle in vertical strips of a sprite's width (csrc/par_strips.h), with the
+    divisions done through the hardware's approximate reciprocal. tools/stripcheck.hip, built from the same header,
+    compares strip, column and row of EVERY pixel of EVERY rectangle shape (1..160 x 1..160: 166 million pixels)
+    with plain integer arithmetic on the GPU, and that the idle lanes past a rectangle keep their strip in range."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "stripcheck")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off",
+                    "-I", os.path.join(root, "pixel-art-raytracer_amd", "csrc"), "-o", exe,
+                    os.path.join(root, "tools", "stripcheck.hip")], check=True, capture_output=True, timeout=300)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "165894400 pixels" in p.stdout and ": 0 mismatches" in p.stdout, p.stdout
