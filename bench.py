@@ -28,6 +28,7 @@ beside the headline.
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import datetime
 import importlib
 import json
 import os
@@ -199,7 +200,8 @@ def main():
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group(args.backend)
+            # (the test backend: a rank that is lost fails the job in minutes, not after gloo's default half hour)
+            dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=240))
 
     par = importlib.import_module("pixel-art-raytracer_amd")
     T = par.types
@@ -284,10 +286,21 @@ def main():
         hit_pixels = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
     barrier()
 
-    # clock ramp (time-based, untimed): the GPU's clocks and the host's caches settle before anything is counted
+    # clock ramp (time-based, untimed): the GPU's clocks and the host's caches settle before anything is counted.
+    # With N > 1 every iteration holds collectives, so the ranks must run the SAME number of iterations: each rank
+    # says whether its own clock wants another one and all of them take the maximum (one small all-reduce per
+    # iteration) -- a rank deciding from its own clock alone could run one iteration more than the others and leave
+    # the job with unmatched gathers. PAR_BENCH_RAMP_SKEW (tests): rank r asks for that many seconds x r more, which
+    # makes the ranks' wishes differ on purpose.
+    ramp_s = 0.6 + float(os.environ.get("PAR_BENCH_RAMP_SKEW", "0")) * rank
     t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < 0.6:
+    ramp_iterations = 0
+    while True:
         run_block(0, 4 * depth)
+        ramp_iterations += 1
+        more = 1.0 if time.perf_counter() - t_ramp < ramp_s else 0.0
+        if reduce_max(more) == 0.0:
+            break
     # warm-up (untimed, counted)
     run_block(0, max(args.warmup, 1))
 
@@ -358,11 +371,14 @@ def main():
         names = [None] * world
         dist.all_gather_object(names, f"rank {rank}: {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank}), "
                                       f"rows {r0}..{r1}")
+        ramp_counts = [None] * world
+        dist.all_gather_object(ramp_counts, ramp_iterations)
         worst_render = reduce_max(render_ms)
         if rank == 0:
             out["multi_gpu"] = {
                 "render_ms": round(worst_render, 5), "gather_ms": round(gather_ms, 5),
                 "gather_bytes_per_rank": int(gather.max_rows * W * 4), "ranks_seen": names,
+                "ramp_iterations": ramp_counts,  # (untimed clock ramp: the same on every rank by construction)
                 "note": "render_ms: one frame's row block rendered and waited for, one at a time (maximum over ranks); "
                         "gather_ms: one gather of the blocks to rank 0 on its own, waited for; the timed region "
                         "overlaps both over the frames in flight",

@@ -481,12 +481,17 @@ def test_bench_multi_rank_control_flow(world):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", str(world), "--steps", "12", "--warmup", "3", "--blocks", "3", "--backend", "gloo", "--share-gpu",
            "--size", "1000" if world == 3 else "1024", "--no-cpu-baseline"]
-    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    # PAR_BENCH_RAMP_SKEW: the ranks' clocks WANT different numbers of untimed ramp iterations (each holds
+    # collectives); the job only ends if they agree on one number all the same
+    p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PAR_BENCH_RAMP_SKEW="0.25"))
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == world and d["steps"] == 12 and d["verified_vs_single_gpu_frame"] is True
     assert d["value"] > 0 and d["scaling"] == "strong"
+    ramp = d["multi_gpu"]["ramp_iterations"]
+    assert len(ramp) == world and len(set(ramp)) == 1 and ramp[0] >= 1, ramp  # every rank ran the same number
     mg = d["multi_gpu"]
     assert len(mg["ranks_seen"]) == world and mg["render_ms"] > 0 and mg["gather_ms"] > 0
     assert mg["gather_bytes_per_rank"] > 0 and d["ms_per_step_spread"]["blocks"] == 3
