@@ -181,6 +181,9 @@ def main():
     W = H = L = args.size
     N_PRIMS = args.prims
     os.environ.setdefault("PAR_DEBUG_STAMPS", "1")  # allocates the stamp buffers; stamps are taken on request only
+    # RCCL between processes needs dmabuf IPC on this host driver (exported by the image; kept if a launcher drops it;
+    # it has to be in place before the HIP runtime starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
