@@ -1184,12 +1184,16 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         const float dot = nx * tx + ny * ty + nz * tz;                     // alt:746-747 (no contraction)
         const float diffuse = std_max(0.f, dot);                           // alt:745
         b_lit = std_min(1.f, diffuse + ambient);                           // alt:758
-        sy = div_bin(H - wy - wz, a.magic_b);                              // alt:725-726
+        // alt:725-726: the start bin's row is bin(H - wy - wz). wy + wz is world_j whatever the texel's depth (it is
+        // subtracted from y and added to z, alt:356-361), and H - world_j is the pixel's screen row (alt:280; no
+        // view is taller than a `short` holds, par_create): a row of this column's tile, whose bin row is `by`. The
+        // overflow path keeps the division.
+        sy = GENERIC ? div_bin(H - wy - wz, a.magic_b) : by;
         sz = div_bin(wz, a.magic_b);                                       // alt:727
         ox = (int)(int16_t)col; oy = (int)(int16_t)p_y; oz = (int)(int16_t)p_z;  // alt:720-722
         // shadow ray, alt:738-742: columns_kernel has walked from every occupied bin of the column
         int woff = 0, wcnt = -1;
-        if (!GENERIC && sy == by) {
+        if (!GENERIC) {
             for (int n = 0; n < n_nb; n++) {
                 const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)cr.nb.x, n);
                 const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)cr.nb.y, n);
