@@ -355,6 +355,15 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.ambient = c->params.ambient;
     a.background = c->params.background;
     a.flags = flags;
+    // Chunks per work item of a column visited as a whole tile: a frame with many chunks (a dense scene) lets a
+    // wavefront read what a column's chunks share once for several of them; a frame with few needs every wavefront it
+    // can get. PAR_TUNE_TILE_K overrides (tools).
+    static const int tuned_k = [] {
+        const char* e = std::getenv("PAR_TUNE_TILE_K");
+        const int v = e ? std::atoi(e) : 0;
+        return v < 0 ? 0 : (v > 64 ? 64 : v);
+    }();
+    a.tile_k = tuned_k > 0 ? tuned_k : (c->total_items >= 65536 ? 5 : (c->total_items >= 16384 ? 3 : (c->total_items >= 4096 ? 2 : 1)));
     a.dyn = make_dyn(c, c->light);
     a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;
     a.count = c->grid.count[set];

@@ -49,6 +49,20 @@ struct par_walkrec {
 };
 static_assert(sizeof(par_walkrec) == 32, "walk record layout");
 
+// An entry of a column as the TILE pass of the render kernel reads it: one scalar load of eight dwords per candidate
+// entry, every field in the form the per-pixel test (alt:310-346) consumes, nothing to unpack or add up per chunk.
+struct par_xent {
+    int32_t px4;     // 4 * px: the pixel's column and the texel offsets are kept in bytes of an int32 table
+    int32_t dims;    // 4 * ex | (ey + ez) << 8: width (bytes) and height of the sprite rectangle, alt:310-317
+    int32_t top;     // py + ey + pz + ez: sprite row = top - world_j, alt:324-326
+    int32_t k;       // ey - top: min(0, ey - sprite row) = min(0, k + world_j), alt:338-340
+    int32_t dbase;   // py - pz, alt:336-337
+    int32_t pz;      // the pixel's z = pz + texel depth, its y = world_j - z (alt:356-361)
+    int32_t entity;  // alt:363
+    int32_t bzk;     // bin_z | run << 16; run = empty stretches of the column before the entry's bin (alt:298-300)
+};
+static_assert(sizeof(par_xent) == 32, "one s_load_dwordx8 per entry");
+
 struct par_colrec_nb {
     int16_t bz;          // bin_z of an occupied bin of the column, ascending
     uint8_t off, cnt;    // its records: entries[off, off+cnt)
@@ -66,6 +80,10 @@ struct par_colrec {
     int16_t ebz[PAR_COL_ENT];  // bin_z of each entry (the primary pass walks the entries as one flat list)
     par_slot entries[PAR_COL_ENT];
     par_walkrec walk[PAR_COL_WALK];
+    // the tile pass's view of the entries (written for columns visited as whole tiles):
+    uint32_t rect[PAR_COL_ENT];  // the entry's sprite rectangle clipped to the tile, relative to the tile's corner
+                                 // (bx * B, by * B): row0 | row1 << 8 | col0 << 16 | col1 << 24, ends exclusive
+    par_xent xent[PAR_COL_ENT];
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");
@@ -107,7 +125,8 @@ struct par_item {
     uint32_t ci;        // index of the column (list and record), or PAR_ITEM_NONE
     uint32_t visit;     // (pass << 16) | chunk of the pass
     uint32_t where;     // bx | by << 10 | PAR_ITEM_SIMPLE
-    uint32_t bins;      // simple columns: first | last << 16 of the (contiguous) occupied bins
+    uint32_t bins;      // simple columns: first | last << 16 of the (contiguous) occupied bins; tile items: the
+                        // number of consecutive 64-pixel chunks the item covers, from chunk `visit & 0xFFFF` on
     par_slot entry;     // the pass's entry (entry passes)
 };
 static_assert(sizeof(par_item) == 32, "work item layout");
@@ -157,6 +176,7 @@ struct par_render_args {
     float ambient;
     uint32_t background;           // gray level (alt:281)
     uint32_t flags;
+    int32_t tile_k;                // 64-pixel chunks per work item of a column visited as a whole tile (>= 1)
     par_frame_dyn dyn;             // used when dyn_ptr == nullptr
     const par_frame_dyn* dyn_ptr;  // graph path
     const uint8_t* count;

@@ -605,7 +605,11 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     const int pass_chunks = __shfl(chunk_incl, 63);
     const int first_item = chunk_incl - my_chunks;
     const int tile_mode = (pass_chunks >= tile_chunks) ? 1 : 0;
-    const int n_items = (overflow || role != 0) ? 0 : (tile_mode ? tile_chunks : pass_chunks);
+    // a whole-tile visit is listed as items of tile_k consecutive chunks each (what a column's chunks share is then
+    // read once per item, render_tile_item), an entry-by-entry visit as one item per chunk
+    const int tile_k = max(a.tile_k, 1);
+    const int tile_items = (tile_chunks + tile_k - 1) / tile_k;
+    const int n_items = (overflow || role != 0) ? 0 : (tile_mode ? tile_items : pass_chunks);
     int item_base = 0;
     if (lane == 0 && n_items > 0) item_base = atomicAdd(&g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], n_items);
 
@@ -674,7 +678,8 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
         if (tile_mode) {
             it.entry = par_slot{0, 0, 0, 0, 0, 0, 0};
             for (int k = lane; k < n_items; k += 64) {
-                it.visit = (PAR_ITEM_TILE << 16) | (uint32_t)k;
+                it.visit = (PAR_ITEM_TILE << 16) | (uint32_t)(k * tile_k);
+                it.bins = (uint32_t)min(tile_k, tile_chunks - k * tile_k);
                 if (item_base + k < g.item_capacity) dst[k] = it;
             }
         } else {
@@ -705,6 +710,32 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
             if (lane < n_entries) {
                 rec->entries[lane] = sm.entries[lane];
                 rec->ebz[lane] = sm.ebz[lane];
+            }
+            if (tile_mode) {
+                // the tile pass's view of the entries (par_xent, rect): every sum and difference the per-pixel test
+                // needs, and how many EMPTY stretches of the column lie before the entry's bin (an empty bin
+                // between two visited bins resets `adjacent`, alt:298-300; occupied bins in between do not)
+                const int bz = lane < n_entries ? (int)sm.ebz[lane] : 0;
+                const int prev_bz = __shfl_up(bz, 1);
+                const uint64_t gap_mask = __ballot(lane > 0 && lane < n_entries && bz != prev_bz && bz != prev_bz + 1);
+                if (lane < n_entries) {
+                    const par_slot r = sm.entries[lane];
+                    const int top = r.py + r.ey + r.pz + r.ez;
+                    par_xent x;
+                    x.px4 = 4 * r.px;
+                    x.dims = (4 * r.ex) | ((r.ey + r.ez) << 8);
+                    x.top = top;
+                    x.k = r.ey - top;
+                    x.dbase = r.py - r.pz;
+                    x.pz = r.pz;
+                    x.entity = r.entity;
+                    x.bzk = bz | (__popcll(gap_mask & ((2ull << lane) - 1ull)) << 16);
+                    rec->xent[lane] = x;
+                    const int ty = by * a.B;
+                    const int r0 = min(max(a.H - top - ty, 0), a.B), r1 = min(max(a.H - (r.py + r.pz) - ty, 0), a.B);
+                    const int q0 = min(max(r.px - c0, 0), a.B), q1 = min(max(r.px + r.ex - c0, 0), a.B);
+                    rec->rect[lane] = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)q0 << 16) | ((uint32_t)q1 << 24);
+                }
             }
         }
     }
@@ -1033,7 +1064,9 @@ struct OwnTexel {
 // counting); the production kernels are compiled without them.
 // IDS: the scene may have a sprite-id table (looked at at run time); without one (the render launch knows) every
 // entity uses sprite 0 and the table arithmetic (two 32-bit multiplies per candidate entry) is compiled out.
-template <bool GENERIC, bool DBG, bool IDS = true>
+// FULL: the parity planes (brightness, lit, G-buffer) may be asked for; a production frame (RGBA + palette index)
+// runs kernels compiled without them (their pointers cost scalar registers the hot loops need).
+template <bool GENERIC, bool DBG, bool IDS = true, bool FULL = true>
 __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_render_args& a, const par_colrec& rec_,
                                              const ColumnRegs& cr, uint64_t dup, const par_frame_dyn& dyn,
                                              int n_entries, int n_nb, int bx, int by, int own, int col, int row,
@@ -1290,9 +1323,9 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         const size_t o = (size_t)(row - a.row_begin) * W + col;
         if (a.out.fb) __builtin_nontemporal_store(color_scale(rgba, bright), reinterpret_cast<uint32_t*>(a.out.fb) + o);
         if (a.out.palidx) __builtin_nontemporal_store((uint8_t)pal_index, a.out.palidx + o);
-        if (a.out.brightness) a.out.brightness[o] = bright;
-        if (a.out.lit) a.out.lit[o] = lit_px ? 1 : 0;
-        if (a.out.gbuf) {
+        if (FULL && a.out.brightness) a.out.brightness[o] = bright;
+        if (FULL && a.out.lit) a.out.lit[o] = lit_px ? 1 : 0;
+        if (FULL && a.out.gbuf) {
             par_pixel pxl;
             pxl.normal = par_vec3{nx, ny, nz};
             pxl.color.red = (uint8_t)(rgba & 0xFF);
@@ -1355,7 +1388,7 @@ __device__ __forceinline__ void render_column_generic(const par_grid_dev& g, con
 // (v_readlane). No LDS, no barrier, no loop over chunks: every wavefront of the launch is a handful of dependent
 // loads long, whatever its column looks like.
 // The item as two 16-byte words (par_item: {ci, visit, where, bins}, {entry}).
-template <bool DBG, bool IDS>
+template <bool DBG, bool IDS, bool FULL>
 __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, uint4 ib,
                                             int lane) {
     const uint32_t fl = DBG ? a.flags : 0u;
@@ -1363,7 +1396,7 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const uint32_t pass = ia.y >> 16;
     const int chunk = (int)(ia.y & 0xFFFFu);
     const bool simple = (ia.z & PAR_ITEM_SIMPLE) != 0;
-    const bool tile_mode = pass == PAR_ITEM_TILE;
+    constexpr bool tile_mode = false;  // (whole-tile visits are render_tile_item's)
     const par_colrec& rec_ = g.colrec[ci];
     // ---- everything the ITEM says: the column, the rectangle visited, this lane's pixel, and (entry passes) the
     // texel of the pass's own entry, the likeliest winner of the pixel. Its depth, normal, colour and palette index
@@ -1461,14 +1494,282 @@ __device__ __forceinline__ void render_item(const par_grid_dev& g, const par_ren
     const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
     // (a simple column's only entry sits in every lane: it is read as entry 0 whatever its index in the record was)
     const int own = tile_mode ? -1 : (simple ? 0 : (int)pass);
-    render_chunk<false, DBG, IDS>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, col_lo, col_hi, valid,
+    render_chunk<false, DBG, IDS, FULL>(g, a, rec_, cr, dup, dyn, n_entries, n_nb, bx, by, own, col, row, row_lo, row_hi, col_lo, col_hi, valid,
                              lane, nullptr, pre);
     asm volatile("" ::"v"(touched));  // (keeps the touch alive; nothing reads it)
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// render_tile_item: a work item of a column that is visited as a WHOLE TILE (every pixel of the bin's footprint; the
+// dense regime: a floor, a wall of boxes): `n_chunks` consecutive 64-pixel chunks of the strip order, one pixel per
+// lane. This path is bound by instruction ISSUE, not by latency (tools/issuebench.hip has the prices: a scalar
+// instruction costs a SIMD as much as a vector one, a vector instruction with a scalar operand twice a plain one,
+// a vector load of 16 bytes per lane sixteen times), so it is written around the wave-uniformity of everything but
+// the pixel:
+//   - what the chunks of a column share (record header, entry rectangles, bin table) is read once per item;
+//   - the candidate entries of a chunk are read with ONE scalar load each (par_xent: every sum the test needs);
+//   - the per-pixel booleans of the primary pass (done, hit in this bin, adjacent, alt:282-374) are lane MASKS in
+//     scalar registers: the bin bookkeeping costs no vector instruction;
+//   - the shadow test groups the lanes by start bin (nearly always one group) and reads that bin's walk list with
+//     scalar loads: no per-lane record loads, no address arithmetic, no unpacking.
+// Same arithmetic, in the same order, as render_chunk (alt:310-365, 704-758).
+// ------------------------------------------------------------------------------------------------------------
+typedef uint64_t lanemask;
+__device__ __forceinline__ bool lane_of(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// todo &= ~(1 << e) in ONE scalar instruction (the compiler's todo & (todo - 1) is three)
+__device__ __forceinline__ lanemask mask_clear(lanemask m, int e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(e));
+#else
+    m &= ~(1ull << e);
+#endif
+    return m;
+}
+// The hardware's min / max without the canonicalising v_max x, x the compiler puts in front of fminf / fmaxf when it
+// cannot see where their operands come from (they are products of this wavefront: never signalling NaNs).
+__device__ __forceinline__ float hw_min(float x, float y) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ float hw_max(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+__device__ __forceinline__ float hw_min3(float x, float y, float z) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ float hw_max3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+
+template <bool DBG, bool IDS, bool FULL>
+__device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, int lane) {
+    const uint32_t fl = DBG ? a.flags : 0u;
+    const int ci = (int)ia.x;
+    const int chunk0 = (int)(ia.y & 0xFFFFu);
+    const int n_chunks = (int)ia.w;
+    const par_colrec& rec_ = g.colrec[ci];
+    const int W = a.W, H = a.H, B = a.B;
+    const int bx = (int)(ia.z & 0x3FFu), by = (int)((ia.z >> 10) & 0x3FFu);
+    const int c0 = bx * B, ty = by * B;
+    const int tw = min(B, W - c0);
+    const int rows_lo = max(ty, a.row_begin), rows_hi = min(min(ty + B, H), a.row_end);
+    const int rh = rows_hi - rows_lo;
+    if (tw <= 0 || rh <= 0) return;
+    const int area = tw * rh;
+    // ---- once per item: the record's header (two scalar loads) and its per-lane tables ---------------------------
+    const uint4 h0 = ld_uniform(reinterpret_cast<const uint4*>(&rec_));
+    const uint4 h1 = ld_uniform(reinterpret_cast<const uint4*>(&rec_) + 1);
+    if ((h0.y >> 16) != 0) return;  // overflow: render_overflow_kernel's
+    const int n_nb = (int)(int16_t)(h0.x & 0xFFFFu);
+    const int n_entries = (fl & (1u << 24)) ? 0 : (int)(int16_t)(h0.x >> 16);  // bit 24: ablation (timing only)
+    const uint64_t dup = ((uint64_t)h1.z << 32) | h1.y;
+    const uint32_t rect = rec_.rect[lane];                                          // lane e: entry e's rectangle
+    const uint2 nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];  // lane n: occupied bin n
+    const int nb_bz = (int)(int16_t)(nb.x & 0xFFFFu);
+    // entry rectangles relative to the tile's corner (ends exclusive); rows of the visit start at rows_lo
+    const int e_r0 = (int)(rect & 0xFFu), e_r1 = (int)((rect >> 8) & 0xFFu);
+    const int e_q0 = (int)((rect >> 16) & 0xFFu), e_q1 = (int)(rect >> 24);
+    const lanemask eligible = __ballot(lane < n_entries) & ~dup & __ballot(e_r1 > e_r0) & __ballot(e_q1 > e_q0);
+    const lanemask nb_lanes = __ballot(lane < n_nb);
+    const int row_off = rows_lo - ty;
+    const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
+    const float ambient = a.ambient;
+    const char* depth0 = reinterpret_cast<const char*>(a.sprites[0].depth);
+    const par_xent* xent = rec_.xent;
+    const par_walkrec* walk = rec_.walk;
+    const par_strips st = par_strips_of(tw);
+    // the planes, addressed from the visited rectangle's corner with 32-bit pixel offsets
+    const size_t corner = (size_t)(rows_lo - a.row_begin) * (size_t)W + (size_t)c0;
+
+    for (int c = chunk0; c < chunk0 + n_chunks; c++) {  // (wave-uniform)
+        const int p_first = c * 64;
+        if (p_first >= area) break;
+        const int last_lane = min(63, area - 1 - p_first);
+        const int pidx = p_first + lane;
+        int strip, colr, rowr;
+        par_strip_pixel(st, rh, pidx, strip, colr, rowr);
+        // the chunk's box (wave-uniform), in tile coordinates: the rows and columns of its first and last pixel when
+        // both lie in one strip, the whole rectangle otherwise
+        const int strip_a = __builtin_amdgcn_readfirstlane(strip), strip_b = __builtin_amdgcn_readlane(strip, last_lane);
+        int box_r0 = row_off, box_r1 = row_off + rh - 1, box_q0 = 0, box_q1 = tw - 1;
+        if (strip_a == strip_b) {
+            box_r0 = row_off + __builtin_amdgcn_readfirstlane(rowr);
+            box_r1 = row_off + __builtin_amdgcn_readlane(rowr, last_lane);
+            box_q0 = strip_a * st.sw;
+            box_q1 = box_q0 + (strip_a == st.n_strips - 1 ? st.lw : st.sw) - 1;
+        }
+        const int col = c0 + colr, row = rows_lo + rowr;
+        const int wj = H - row;  // world_j, alt:280 (1 <= wj <= H <= 32767)
+        const int col4 = col << 2;
+
+        // ---- primary ray, alt:271-397: the candidate entries front to back -------------------------------------
+        lanemask todo = __ballot(e_r0 <= box_r1) & __ballot(e_r1 > box_r0) & __ballot(e_q0 <= box_q1) &
+                        __ballot(e_q1 > box_q0) & eligible;
+        lanemask done = ~__ballot(pidx < area);  // lanes that look at no further entry (alt:372-374, or no pixel)
+        lanemask adj1 = 0;                       // adjacent == 1 (alt:282, 368)
+        lanemask hit_bin = 0;                    // hit_in_bin (alt:303, 365)
+        int cur_bzk = -1;
+        int closest = INT_MIN;                   // alt:289
+        int w_d = 0, w_pz = 0, w_ent = 0, w_t4 = 0;
+        while (todo) {
+            const int e = __builtin_ctzll(todo);
+            todo = mask_clear(todo, e);
+            const u32x8 x = ld_uniform(reinterpret_cast<const u32x8*>(xent + e));
+            const int bzk = (int)x[7];
+            if (bzk != cur_bzk) {  // the previous visited bin is complete (alt:368-374), across the bins skipped
+                done |= adj1 & hit_bin;                        // adjacent reaches 2
+                adj1 |= hit_bin;
+                if (((bzk ^ cur_bzk) >> 16) != 0) adj1 = 0;    // an empty bin lies in between (alt:298-300)
+                hit_bin = 0;
+                cur_bzk = bzk;
+                if (done == ~0ull) break;  // wavefront early-out (`done` only changes here)
+            }
+            const int dx4 = col4 - (int)x[0];
+            const int srow = (int)x[2] - wj;                                               // alt:324-326
+            const uint32_t ex4 = x[1] & 0xFFu, eh = x[1] >> 8;
+            // alt:310-317 as two unsigned range tests
+            const lanemask in = __ballot((uint32_t)dx4 < ex4) & __ballot((uint32_t)srow < eh) & ~done;
+            const uint32_t t4 = (uint32_t)(srow * (4 * PAR_SPRITE_W) + dx4);                // alt:330-332, in bytes
+            int sid = 0;
+            if (IDS && a.sprite_ids) sid = ld_uniform(a.sprite_ids + (int)x[6]);          // alt:321-322
+            const char* dtab = (!IDS || sid == 0) ? depth0 : reinterpret_cast<const char*>(a.sprites[sid].depth);
+            // (every lane loads: a lane outside the rectangle reads texel 0 and its result is not used)
+            const int d = *reinterpret_cast<const int32_t*>(dtab + (lane_of(in) ? t4 : 0u));
+            const int depth = (int)x[4] + min(0, (int)x[3] + wj) - d;                      // alt:336-341
+            const lanemask better = __ballot(closest < depth) & in;                        // alt:344-346
+            if (lane_of(better)) {
+                closest = depth;
+                w_d = d;
+                w_pz = (int)x[5];                                                          // alt:360-361
+                w_ent = (int)x[6];                                                         // alt:363
+                w_t4 = (int)(t4 + (uint32_t)sid * (uint32_t)(4 * PAR_SPRITE_TEXELS));
+            }
+            hit_bin |= better;                                                             // alt:365
+        }
+        // (a pixel was hit exactly when `closest` moved: the comparison alt:344 is strict)
+        lanemask hit = __ballot(closest != INT_MIN);
+        if (fl & (1u << 26)) hit = 0;  // bit 26: ablation (timing experiments only), no shading
+        if (!hit) continue;
+
+        // ---- shading, alt:704-758 ------------------------------------------------------------------------------
+        const bool is_hit = lane_of(hit);
+        const int p_z = w_pz + w_d;      // alt:360-361
+        const int p_y = wj - p_z;        // alt:356-359: y + z == world_j
+        const int p_tex = w_t4 >> 2;
+        par_texel ti = par_texel{0.f, 0.f, 0.f, 0u};
+        int pal_index = PAR_PALIDX_BACKGROUND;
+        float inv_x = 0.f, inv_y = 0.f, inv_z = 0.f, b_lit = 0.f;
+        int sz = 0;
+        if (is_hit) {
+            ti = a.texinfo[p_tex];                                                          // alt:349-354
+            if (a.out.palidx) {
+                const int sid = IDS ? p_tex / PAR_SPRITE_TEXELS : 0;
+                pal_index = a.sprites[sid].color[p_tex - sid * PAR_SPRITE_TEXELS];
+            }
+            // towards_light = normalize_L1(light - world), alt:711-715 + spr:28-35
+            const float dx = (float)(dyn.lx - col), dy = (float)(dyn.ly - p_y), dz = (float)(dyn.lz - p_z);
+            float tx, tyy, tz;
+            normalize_l1_and_inverse(dx, dy, dz, tx, tyy, tz, inv_x, inv_y, inv_z);       // alt:711-719
+            const float dot = ti.nx * tx + ti.ny * tyy + ti.nz * tz;                        // alt:746-747
+            const float diffuse = std_max(0.f, dot);                                        // alt:745
+            b_lit = std_min(1.f, diffuse + ambient);                                        // alt:758
+            sz = div_bin(p_z, a.magic_b);                                                   // alt:727
+        }
+        // shadow ray, alt:738-742: the lanes grouped by start bin (bx, by, sz); the bin's walk list (columns kernel)
+        // through scalar loads. The start bin's row is the column's own (y + z == world_j, alt:725-726).
+        const float fox = (float)(int)(int16_t)col, foy = (float)(int)(int16_t)p_y, foz = (float)(int)(int16_t)p_z;  // alt:720-722
+        lanemask lit = hit;
+        lanemask pending = hit;
+        const lanemask not_finite = (__ballot(!__builtin_isfinite(inv_x)) | __ballot(!__builtin_isfinite(inv_y)) |
+                                     __ballot(!__builtin_isfinite(inv_z))) & hit;
+        while (pending) {
+            const int s_bin = __builtin_amdgcn_readlane(sz, __builtin_ctzll(pending));
+            const lanemask grp = __ballot(sz == s_bin) & pending;
+            pending &= ~grp;
+            const lanemask m = __ballot(nb_bz == s_bin) & nb_lanes;
+            int woff = 0, wcnt = -1;
+            if (m) {
+                const uint32_t wd = (uint32_t)__builtin_amdgcn_readlane((int)nb.y, __builtin_ctzll(m));
+                woff = (int)(wd & 0xFFFFu);
+                wcnt = (int)(int16_t)(wd >> 16);  // -1: the walk was too long to record
+            }
+            if (wcnt < 0) {
+                // a start bin that holds no primitive (negative world z, sprite depths outside the box) or whose walk
+                // was too long to record: trace_hash_for_light as written, per lane
+                bool l = true;
+                if (lane_of(grp)) {
+                    l = lane_shadow_walk(g, a.count, a.slots, bx, by, s_bin, dyn, w_ent, (int)(int16_t)col,
+                                         (int)(int16_t)p_y, (int)(int16_t)p_z, inv_x, inv_y, inv_z);
+                }
+                lit &= ~(__ballot(!l) & grp);
+                continue;
+            }
+            const par_walkrec* wr = walk + woff;
+            for (int r = 0; r < wcnt; r++) {
+                const u32x8 w = ld_uniform(reinterpret_cast<const u32x8*>(wr + r));
+                const v2f rx = {__uint_as_float(w[0]), __uint_as_float(w[1])};
+                const v2f ry = {__uint_as_float(w[2]), __uint_as_float(w[3])};
+                const v2f rz = {__uint_as_float(w[4]), __uint_as_float(w[5])};
+                const v2f tx = (rx - fox) * inv_x, ty2 = (ry - foy) * inv_y, tz = (rz - foz) * inv_z;  // alt:49-72
+                lanemask occl;
+                if (!not_finite) {
+                    // no NaN can arise (slab_hit): the mathematical min / max, by the hardware's instructions
+                    const float tmin = hw_max3(hw_min(tx.x, tx.y), hw_min(ty2.x, ty2.y), hw_min(tz.x, tz.y));
+                    const float tmax = hw_min3(hw_max(tx.x, tx.y), hw_max(ty2.x, ty2.y), hw_max(tz.x, tz.y));
+                    occl = __ballot(tmax >= tmin);
+                } else {  // (an axis-parallel light direction, 1 / 0, takes the reference's own sequence, alt:55-82)
+                    float tmin = std_min(tx.x, tx.y);
+                    float tmax = std_max(tx.x, tx.y);
+                    tmin = std_max(tmin, std_min(ty2.x, ty2.y));
+                    tmax = std_min(tmax, std_max(ty2.x, ty2.y));
+                    tmin = std_max(tmin, std_min(tz.x, tz.y));
+                    tmax = std_min(tmax, std_max(tz.x, tz.y));
+                    occl = __ballot(tmax >= tmin);
+                }
+                lit &= ~(occl & __ballot((int)w[6] != w_ent) & grp);                        // alt:484-491
+                if ((lit & grp) == 0) break;
+            }
+        }
+        // ---- quantise + store, alt:735, 757-758 ----------------------------------------------------------------
+        if (DBG && (fl & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
+            if (lane == 0) atomicAdd(a.ray_counter, (unsigned long long)__popcll(hit));
+        }
+        const bool lit_px = lane_of(lit);
+        const float bright = lit_px ? b_lit : ambient;
+        if (DBG && (fl & (1u << 25))) {  // bit 25: ablation (timing only), no stores; keep the values alive
+            asm volatile("" ::"v"(ti.rgba), "v"(bright), "v"(pal_index));
+        } else if (is_hit) {  // (uncovered pixels keep what the fill wrote)
+            const uint32_t o = (uint32_t)(rowr * W + colr);  // (below 2^23: a tile has at most 160 rows)
+            if (a.out.fb) __builtin_nontemporal_store(color_scale(ti.rgba, bright), reinterpret_cast<uint32_t*>(a.out.fb) + corner + o);
+            if (a.out.palidx) __builtin_nontemporal_store((uint8_t)pal_index, a.out.palidx + corner + o);
+            if (FULL && a.out.brightness) a.out.brightness[corner + o] = bright;
+            if (FULL && a.out.lit) a.out.lit[corner + o] = lit_px ? 1 : 0;
+            if (FULL && a.out.gbuf) {
+                par_pixel pxl;
+                pxl.normal = par_vec3{ti.nx, ti.ny, ti.nz};
+                pxl.color.red = (uint8_t)(ti.rgba & 0xFF);
+                pxl.color.green = (uint8_t)((ti.rgba >> 8) & 0xFF);
+                pxl.color.blue = (uint8_t)((ti.rgba >> 16) & 0xFF);
+                pxl.color.alpha = (uint8_t)(ti.rgba >> 24);
+                pxl.y = p_y;
+                pxl.z = p_z;
+                pxl.entity_index = w_ent;
+                a.out.gbuf[corner + o] = pxl;
+            }
+        }
+    }
+}
+
 // Wavefront `w` of `n_waves` (a multiple of PAR_ITEM_SHARDS): items w / shards, + n_waves / shards, ... of shard
 // w mod shards. The launch offers one wavefront per item of the host's bound, so the loop normally runs once.
-template <bool DBG, bool IDS>
+template <bool DBG, bool IDS, bool FULL>
 __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
     const int lane = (int)threadIdx.x & 63;
     const int shard = w & (PAR_ITEM_SHARDS - 1);
@@ -1481,7 +1782,11 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     stamp(g, DBG ? a.flags : 0u, 3, 1);
     for (int i = first; i < n;) {
         if (it[0] != PAR_ITEM_NONE) {
-            render_item<DBG, IDS>(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
+            if ((it[1] >> 16) == PAR_ITEM_TILE) {
+                render_tile_item<DBG, IDS, FULL>(g, a, make_uint4(it[0], it[1], it[2], it[3]), lane);
+            } else {
+                render_item<DBG, IDS, FULL>(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
+            }
         }
         i += n_waves >> PAR_ITEM_SHARD_BITS;
         if (i < n) {
@@ -1491,13 +1796,13 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     }
 }
 
-template <bool DBG, bool IDS>
+template <bool DBG, bool IDS, bool FULL>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid_dev g, par_render_args a) {
     stamp(g, DBG ? a.flags : 0u, 3, 0);
     const unsigned long long core0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
     const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-    render_items<DBG, IDS>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
+    render_items<DBG, IDS, FULL>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
     stamp(g, DBG ? a.flags : 0u, 3, 7);
     if (DBG && g.stamps && (a.flags & (1u << 29)) && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
         // slot 5: the wavefront's life in shader-clock cycles (s_memtime), beside slots 0 / 7 in 100 MHz ticks
@@ -1536,7 +1841,7 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_
     const int b = (int)blockIdx.x;
     if (b < n_item_wgs) {
         const int w = __builtin_amdgcn_readfirstlane(b * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-        render_items<DBG, true>(g, a, w, n_item_wgs * PAR_WAVE_NW);
+        render_items<DBG, true, true>(g, a, w, n_item_wgs * PAR_WAVE_NW);
         return;
     }
     const int j = b - n_item_wgs;  // (workgroups of this kind exist only when some column may overflow)
@@ -1834,11 +2139,11 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     if (item_bound <= 0 || a.dense) return hipSuccess;
     const dim3 grid((unsigned)item_workgroups(item_bound)), block(PAR_WAVE_NW * 64);
     if (a.flags & PAR_DEBUG_FLAGS) {
-        hipLaunchKernelGGL((render_items_kernel<true, true>), grid, block, 0, stream, g, a);
-    } else if (a.sprite_ids) {
-        hipLaunchKernelGGL((render_items_kernel<false, true>), grid, block, 0, stream, g, a);
-    } else {  // every entity uses sprite 0 (the reference's own scenes)
-        hipLaunchKernelGGL((render_items_kernel<false, false>), grid, block, 0, stream, g, a);
+        hipLaunchKernelGGL((render_items_kernel<true, true, true>), grid, block, 0, stream, g, a);
+    } else if (a.sprite_ids || a.out.brightness || a.out.lit || a.out.gbuf) {
+        hipLaunchKernelGGL((render_items_kernel<false, true, true>), grid, block, 0, stream, g, a);
+    } else {  // every entity uses sprite 0 (the reference's own scenes), RGBA + palette index only
+        hipLaunchKernelGGL((render_items_kernel<false, false, false>), grid, block, 0, stream, g, a);
     }
     return hipGetLastError();
 }
