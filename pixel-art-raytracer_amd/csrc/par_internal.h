@@ -29,6 +29,8 @@ constexpr int PAR_COL_ENT = 64;         // slot records of one column (one per l
 constexpr int PAR_BIN_WALK = 64;        // occluder records of one start bin's shadow walk
 constexpr int PAR_COL_WALK = 160;       // occluder records of all walks of one column
 constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = 160;  // supported bin sizes
+constexpr int PAR_TILE_MASKS = 64;      // chunks of a tile visit whose candidate masks the column record carries (one
+                                        // lane of the column's wavefront each: bins up to 64 pixels a side)
 
 // What the shading pass needs of a sprite texel besides its depth, in one 16-byte record: the normal (spr:70) and
 // the palette colour the texel's index resolves to (spr:68 through color_palette, alt:352-354). Built on the host
@@ -84,6 +86,9 @@ struct par_colrec {
     uint32_t rect[PAR_COL_ENT];  // the entry's sprite rectangle clipped to the tile, relative to the tile's corner
                                  // (bx * B, by * B): row0 | row1 << 8 | col0 << 16 | col1 << 24, ends exclusive
     par_xent xent[PAR_COL_ENT];
+    uint64_t cmask[PAR_TILE_MASKS];  // per 64-pixel chunk of the tile visit (when there are at most PAR_TILE_MASKS):
+                                     // bit e = entry e can cover a pixel of the chunk (its rectangle meets the chunk's
+                                     // box and it repeats no earlier entry's entity)
 };
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");

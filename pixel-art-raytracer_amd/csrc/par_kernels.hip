@@ -512,6 +512,57 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The box of chunk `c` of a tile visit (strip order, par_strips.h), in tile coordinates: the rows and columns of its
+// first and last pixel when both lie in one strip, the whole rectangle otherwise. `row_off`: the visit's first row
+// relative to the tile's.
+__device__ __forceinline__ void tile_chunk_box(const par_strips& st, int tw, int rh, int row_off, int c, int& r0, int& r1,
+                                               int& q0, int& q1) {
+    const int area = tw * rh;
+    const int pf = min(c * 64, area - 1), pl = min(c * 64 + 63, area - 1);
+    int s0, c0, y0, s1, c1, y1;
+    par_strip_pixel(st, rh, pf, s0, c0, y0);
+    par_strip_pixel(st, rh, pl, s1, c1, y1);
+    r0 = row_off; r1 = row_off + rh - 1; q0 = 0; q1 = tw - 1;
+    if (s0 == s1) {
+        r0 = row_off + y0;
+        r1 = row_off + y1;
+        q0 = s0 * st.sw;
+        q1 = q0 + (s0 == st.n_strips - 1 ? st.lw : st.sw) - 1;
+    }
+}
+
+// columns_wave, whole-tile columns of at most PAR_TILE_MASKS chunks: which entries can cover a pixel of each chunk
+// (par_colrec::cmask). Lane c works out chunk c's box; then, chunk by chunk, every lane holds its entry's rectangle
+// against that box (one ballot per chunk). The render kernel reads a chunk's mask with one scalar load.
+__device__ __forceinline__ void tile_candidate_masks(const par_render_args& a, const ColWave& sm, par_colrec* rec,
+                                                     int n_entries, uint64_t dup_mask, int bx, int by, int lane) {
+    const int c0 = bx * a.B, ty = by * a.B;
+    const int tw = min(a.B, a.W - c0);
+    const int rows_lo = max(ty, a.row_begin), rows_hi = min(min(ty + a.B, a.H), a.row_end);
+    const int rh = rows_hi - rows_lo;
+    if (tw <= 0 || rh <= 0) return;
+    const int tile_chunks = (tw * rh + 63) >> 6;
+    const par_strips st = par_strips_of(tw);
+    int b_r0, b_r1, b_q0, b_q1;
+    tile_chunk_box(st, tw, rh, rows_lo - ty, min(lane, tile_chunks - 1), b_r0, b_r1, b_q0, b_q1);
+    int e_r0 = 0, e_r1 = 0, e_q0 = 0, e_q1 = 0;
+    if (lane < n_entries && !((dup_mask >> lane) & 1)) {
+        const par_slot r = sm.entries[lane];
+        const int top = r.py + r.ey + r.pz + r.ez;
+        e_r0 = min(max(a.H - top - ty, 0), a.B); e_r1 = min(max(a.H - (r.py + r.pz) - ty, 0), a.B);
+        e_q0 = min(max(r.px - c0, 0), a.B);      e_q1 = min(max(r.px + r.ex - c0, 0), a.B);
+    }
+    const bool eligible = e_r1 > e_r0 && e_q1 > e_q0;
+    uint64_t mine = 0;
+    for (int c = 0; c < tile_chunks; c++) {
+        const int r0 = __builtin_amdgcn_readlane(b_r0, c), r1 = __builtin_amdgcn_readlane(b_r1, c);
+        const int q0 = __builtin_amdgcn_readlane(b_q0, c), q1 = __builtin_amdgcn_readlane(b_q1, c);
+        const uint64_t m = __ballot(eligible && e_r0 <= r1 && e_r1 > r0 && e_q0 <= q1 && e_q1 > q0);
+        if (lane == c) mine = m;
+    }
+    if (lane < tile_chunks) rec->cmask[lane] = mine;
+}
+
 // `ci`: index into the column list, or (when background rays are traced) n_cols_bound + bx for the walk from the
 // background start bin of bin column bx. `role`: PAR_COL_ROLES wavefronts share a column's walks (role r takes the
 // occupied bins r, r + roles, ... and the r-th part of the record's walk area); role 0 does everything else. The
@@ -623,7 +674,8 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
         for (int i = role; i < n_nb; i += ROLES) {
             const int sz = sm.nb[i].bz;
             const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, sm.chain, sm.stage, i == 0 ? a.flags : 0u);
-            if (n_rec < 0 || n_walk + n_rec > kWalkPart) {
+            // (a list takes an even number of records: the tile pass reads them in pairs, walk_list_lit)
+            if (n_rec < 0 || n_walk + n_rec + (n_rec & 1) > kWalkPart) {
                 // more occluders on the way than the record holds: the pixels that start here walk for themselves
                 // (lane_shadow_walk in the render kernel), the column keeps its record
                 walk_failed = true;
@@ -634,11 +686,13 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
             } else {
                 par_walkrec* dst = g.colrec[ci].walk + walk_lo + n_walk;
                 for (int r = lane; r < n_rec; r += 64) dst[r] = walkrec_of(sm.stage[r]);
+                // a list of odd length repeats its last record behind its end (the result is an OR over the records)
+                if ((n_rec & 1) && lane == 0) dst[n_rec] = walkrec_of(sm.stage[n_rec - 1]);
                 if (lane == 0) {
                     sm.nb[i].woff = (int16_t)(walk_lo + n_walk);
                     sm.nb[i].wcnt = (int16_t)n_rec;
                 }
-                n_walk += n_rec;
+                n_walk += n_rec + (n_rec & 1);
             }
             wave_lds_fence();  // (the next walk overwrites the stage)
         }
@@ -736,6 +790,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
                     const int q0 = min(max(r.px - c0, 0), a.B), q1 = min(max(r.px + r.ex - c0, 0), a.B);
                     rec->rect[lane] = (uint32_t)r0 | ((uint32_t)r1 << 8) | ((uint32_t)q0 << 16) | ((uint32_t)q1 << 24);
                 }
+                if (tile_chunks <= PAR_TILE_MASKS) tile_candidate_masks(a, sm, rec, n_entries, dup_mask, bx, by, lane);
             }
         }
     }
@@ -1548,6 +1603,94 @@ __device__ __forceinline__ float hw_max3(float x, float y, float z) {
     return r;
 }
 
+// A wave-uniform 32-byte record at base + off through the scalar cache (s_load_dwordx8 with a scalar offset: no
+// address arithmetic). Issued where it stands; uniform_wait() before its first use.
+__device__ __forceinline__ u32x8 uniform_fetch8(const void* base, uint32_t off) {
+    u32x8 v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(v) : "s"(base), "s"(off) : "memory");
+#else
+    v = *reinterpret_cast<const u32x8*>(static_cast<const char*>(base) + off);
+#endif
+    return v;
+}
+__device__ __forceinline__ void uniform_wait(u32x8& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a) : : "memory");
+#endif
+}
+__device__ __forceinline__ void uniform_wait(u32x8& a, u32x8& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) : : "memory");
+#endif
+}
+
+// The shadow test of one group of lanes (the lanes of a chunk whose rays start in one bin) against that bin's walk
+// list, the records read with scalar loads, two per step (the column kernel pads a list of odd length with a repeat
+// of its last record): the lanes of `grp` that are still lit afterwards. Called in uniform control flow (the other
+// lanes compute along; their results are masked). AABB::intersect (alt:40-83) per record and lane, the record's own
+// entity skipped (alt:484-487); stops as soon as no lane of the group is lit (the reference's result is an OR over
+// the records).
+// SIGNS: what is known about the group's inverse directions:
+//   0..7  every lane's are finite, and negative on exactly the axes whose bit is set (x: 1, y: 2, z: 4). The slab
+//         products of an axis are then ordered the same way in every lane -- (lo - o) * inv <= (hi - o) * inv for a
+//         positive inverse (lo <= hi, rounding is monotonic), the other way round for a negative one -- so the
+//         min / max of alt:55-82 need no instruction: near and far planes are picked at compile time;
+//   8     finite, signs differ among the lanes: the hardware's min / max (no NaN can arise, slab_hit);
+//   9     some lane's is not finite (an axis-parallel light direction, 1 / 0): the reference's own sequence.
+template <int SIGNS>
+__device__ __forceinline__ lanemask slab_occluded(const u32x8& w, float fox, float foy, float foz, float inv_x,
+                                                  float inv_y, float inv_z, int self) {
+    const v2f rx = {__uint_as_float(w[0]), __uint_as_float(w[1])};
+    const v2f ry = {__uint_as_float(w[2]), __uint_as_float(w[3])};
+    const v2f rz = {__uint_as_float(w[4]), __uint_as_float(w[5])};
+    const v2f tx = (rx - fox) * inv_x, ty = (ry - foy) * inv_y, tz = (rz - foz) * inv_z;  // alt:49-72
+    float tmin, tmax;
+    if (SIGNS < 8) {
+        tmin = hw_max3((SIGNS & 1) ? tx.y : tx.x, (SIGNS & 2) ? ty.y : ty.x, (SIGNS & 4) ? tz.y : tz.x);
+        tmax = hw_min3((SIGNS & 1) ? tx.x : tx.y, (SIGNS & 2) ? ty.x : ty.y, (SIGNS & 4) ? tz.x : tz.y);
+    } else if (SIGNS == 8) {
+        tmin = hw_max3(hw_min(tx.x, tx.y), hw_min(ty.x, ty.y), hw_min(tz.x, tz.y));
+        tmax = hw_min3(hw_max(tx.x, tx.y), hw_max(ty.x, ty.y), hw_max(tz.x, tz.y));
+    } else {  // alt:55-82 as written
+        tmin = std_min(tx.x, tx.y);
+        tmax = std_max(tx.x, tx.y);
+        tmin = std_max(tmin, std_min(ty.x, ty.y));
+        tmax = std_min(tmax, std_max(ty.x, ty.y));
+        tmin = std_max(tmin, std_min(tz.x, tz.y));
+        tmax = std_min(tmax, std_max(tz.x, tz.y));
+    }
+    return __ballot(tmax >= tmin) & __ballot((int)w[6] != self);                               // alt:484-491
+}
+
+template <int SIGNS>
+__device__ __forceinline__ lanemask walk_list_lit(const par_walkrec* wr, int wcnt, lanemask grp, float fox, float foy,
+                                                 float foz, float inv_x, float inv_y, float inv_z, int self) {
+    lanemask alive = grp;
+    uint32_t end = (uint32_t)wcnt * (uint32_t)sizeof(par_walkrec);
+    for (uint32_t off = 0; off < end; off += 2 * (uint32_t)sizeof(par_walkrec)) {  // (wave-uniform)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+s"(off));  // (a scalar counter: the compiler otherwise counts in a vector register)
+#endif
+        u32x8 w0 = uniform_fetch8(wr, off);
+        u32x8 w1 = uniform_fetch8(wr, off + (uint32_t)sizeof(par_walkrec));
+        uniform_wait(w0, w1);
+        const lanemask o0 = slab_occluded<SIGNS>(w0, fox, foy, foz, inv_x, inv_y, inv_z, self);
+        const lanemask o1 = slab_occluded<SIGNS>(w1, fox, foy, foz, inv_x, inv_y, inv_z, self);
+        alive &= ~(o0 | o1);
+        if (alive == 0) end = 0;  // (no lane of the group is lit: done; folded into the bound, one branch per step)
+    }
+    return alive;
+}
+
+// The sprite depth table of sprite `sid` as a buffer resource: a load through it with an offset outside the table
+// returns 0 instead of faulting (the hardware's range check), so the lanes whose pixel lies outside an entry's
+// rectangle need no select in front of the load.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t depth_table(const par_sprite* sprites, int sid) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(sprites[sid].depth), 0,
+                                             (int)(PAR_SPRITE_TEXELS * sizeof(int32_t)), 0x00020000);
+}
+
 template <bool DBG, bool IDS, bool FULL>
 __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, int lane) {
     const uint32_t fl = DBG ? a.flags : 0u;
@@ -1563,85 +1706,98 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
     const int rh = rows_hi - rows_lo;
     if (tw <= 0 || rh <= 0) return;
     const int area = tw * rh;
+    const bool have_masks = ((area + 63) >> 6) <= PAR_TILE_MASKS;  // (the column kernel made the same test)
     // ---- once per item: the record's header (two scalar loads) and its per-lane tables ---------------------------
     const uint4 h0 = ld_uniform(reinterpret_cast<const uint4*>(&rec_));
     const uint4 h1 = ld_uniform(reinterpret_cast<const uint4*>(&rec_) + 1);
     if ((h0.y >> 16) != 0) return;  // overflow: render_overflow_kernel's
     const int n_nb = (int)(int16_t)(h0.x & 0xFFFFu);
-    const int n_entries = (fl & (1u << 24)) ? 0 : (int)(int16_t)(h0.x >> 16);  // bit 24: ablation (timing only)
+    const int n_entries = (int)(int16_t)(h0.x >> 16);
     const uint64_t dup = ((uint64_t)h1.z << 32) | h1.y;
-    const uint32_t rect = rec_.rect[lane];                                          // lane e: entry e's rectangle
     const uint2 nb = reinterpret_cast<const uint2*>(rec_.nb)[lane & (PAR_COL_NB - 1)];  // lane n: occupied bin n
     const int nb_bz = (int)(int16_t)(nb.x & 0xFFFFu);
-    // entry rectangles relative to the tile's corner (ends exclusive); rows of the visit start at rows_lo
-    const int e_r0 = (int)(rect & 0xFFu), e_r1 = (int)((rect >> 8) & 0xFFu);
-    const int e_q0 = (int)((rect >> 16) & 0xFFu), e_q1 = (int)(rect >> 24);
-    const lanemask eligible = __ballot(lane < n_entries) & ~dup & __ballot(e_r1 > e_r0) & __ballot(e_q1 > e_q0);
+    // entry rectangles relative to the tile's corner (ends exclusive), for tiles of more chunks than the record
+    // carries masks for; rows of the visit start at rows_lo
+    int e_r0 = 0, e_r1 = 0, e_q0 = 0, e_q1 = 0;
+    lanemask eligible = 0;
+    if (!have_masks) {
+        const uint32_t rect = rec_.rect[lane];  // lane e: entry e's rectangle
+        e_r0 = (int)(rect & 0xFFu); e_r1 = (int)((rect >> 8) & 0xFFu);
+        e_q0 = (int)((rect >> 16) & 0xFFu); e_q1 = (int)(rect >> 24);
+        eligible = __ballot(lane < n_entries) & ~dup & __ballot(e_r1 > e_r0) & __ballot(e_q1 > e_q0);
+    }
     const lanemask nb_lanes = __ballot(lane < n_nb);
     const int row_off = rows_lo - ty;
     const par_frame_dyn dyn = a.dyn_ptr ? ld_uniform(a.dyn_ptr) : a.dyn;  // (graph replay: uploaded before the frame)
     const float ambient = a.ambient;
-    const char* depth0 = reinterpret_cast<const char*>(a.sprites[0].depth);
     const par_xent* xent = rec_.xent;
     const par_walkrec* walk = rec_.walk;
     const par_strips st = par_strips_of(tw);
+    const bool has_ids = IDS && a.sprite_ids != nullptr;
+    __amdgpu_buffer_rsrc_t dtab = depth_table(a.sprites, 0);
     // the planes, addressed from the visited rectangle's corner with 32-bit pixel offsets
     const size_t corner = (size_t)(rows_lo - a.row_begin) * (size_t)W + (size_t)c0;
 
     for (int c = chunk0; c < chunk0 + n_chunks; c++) {  // (wave-uniform)
         const int p_first = c * 64;
         if (p_first >= area) break;
-        const int last_lane = min(63, area - 1 - p_first);
         const int pidx = p_first + lane;
         int strip, colr, rowr;
         par_strip_pixel(st, rh, pidx, strip, colr, rowr);
-        // the chunk's box (wave-uniform), in tile coordinates: the rows and columns of its first and last pixel when
-        // both lie in one strip, the whole rectangle otherwise
-        const int strip_a = __builtin_amdgcn_readfirstlane(strip), strip_b = __builtin_amdgcn_readlane(strip, last_lane);
-        int box_r0 = row_off, box_r1 = row_off + rh - 1, box_q0 = 0, box_q1 = tw - 1;
-        if (strip_a == strip_b) {
-            box_r0 = row_off + __builtin_amdgcn_readfirstlane(rowr);
-            box_r1 = row_off + __builtin_amdgcn_readlane(rowr, last_lane);
-            box_q0 = strip_a * st.sw;
-            box_q1 = box_q0 + (strip_a == st.n_strips - 1 ? st.lw : st.sw) - 1;
-        }
         const int col = c0 + colr, row = rows_lo + rowr;
         const int wj = H - row;  // world_j, alt:280 (1 <= wj <= H <= 32767)
         const int col4 = col << 2;
+        const lanemask valid = __ballot(pidx < area);
 
         // ---- primary ray, alt:271-397: the candidate entries front to back -------------------------------------
-        lanemask todo = __ballot(e_r0 <= box_r1) & __ballot(e_r1 > box_r0) & __ballot(e_q0 <= box_q1) &
-                        __ballot(e_q1 > box_q0) & eligible;
-        lanemask done = ~__ballot(pidx < area);  // lanes that look at no further entry (alt:372-374, or no pixel)
+        lanemask todo;
+        if (have_masks) {
+            todo = ld_uniform(rec_.cmask + c);
+        } else {
+            int box_r0, box_r1, box_q0, box_q1;
+            tile_chunk_box(st, tw, rh, row_off, c, box_r0, box_r1, box_q0, box_q1);
+            todo = __ballot(e_r0 <= box_r1) & __ballot(e_r1 > box_r0) & __ballot(e_q0 <= box_q1) &
+                   __ballot(e_q1 > box_q0) & eligible;
+        }
+        if (DBG && (fl & (1u << 24))) todo = 0;  // bit 24: ablation (timing only), no primary pass
+        lanemask done = ~valid;                  // lanes that look at no further entry (alt:372-374, or no pixel)
         lanemask adj1 = 0;                       // adjacent == 1 (alt:282, 368)
         lanemask hit_bin = 0;                    // hit_in_bin (alt:303, 365)
         int cur_bzk = -1;
-        int closest = INT_MIN;                   // alt:289
+        // alt:289; a lane that is done or has no pixel accepts no entry: nothing lies above INT_MAX
+        int closest = lane_of(valid) ? INT_MIN : INT_MAX;
         int w_d = 0, w_pz = 0, w_ent = 0, w_t4 = 0;
         while (todo) {
             const int e = __builtin_ctzll(todo);
             todo = mask_clear(todo, e);
-            const u32x8 x = ld_uniform(reinterpret_cast<const u32x8*>(xent + e));
+            u32x8 x = uniform_fetch8(xent, (uint32_t)e * (uint32_t)sizeof(par_xent));
+            uniform_wait(x);
             const int bzk = (int)x[7];
             if (bzk != cur_bzk) {  // the previous visited bin is complete (alt:368-374), across the bins skipped
-                done |= adj1 & hit_bin;                        // adjacent reaches 2
+                const lanemask fin = adj1 & hit_bin & ~done;   // adjacent reaches 2
+                if (fin) {
+                    closest = lane_of(fin) ? INT_MAX : closest;
+                    done |= fin;
+                    if (done == ~0ull) todo = 0;  // wavefront early-out
+                }
                 adj1 |= hit_bin;
                 if (((bzk ^ cur_bzk) >> 16) != 0) adj1 = 0;    // an empty bin lies in between (alt:298-300)
                 hit_bin = 0;
                 cur_bzk = bzk;
-                if (done == ~0ull) break;  // wavefront early-out (`done` only changes here)
             }
             const int dx4 = col4 - (int)x[0];
             const int srow = (int)x[2] - wj;                                               // alt:324-326
             const uint32_t ex4 = x[1] & 0xFFu, eh = x[1] >> 8;
             // alt:310-317 as two unsigned range tests
-            const lanemask in = __ballot((uint32_t)dx4 < ex4) & __ballot((uint32_t)srow < eh) & ~done;
+            const lanemask in = __ballot((uint32_t)dx4 < ex4) & __ballot((uint32_t)srow < eh);
             const uint32_t t4 = (uint32_t)(srow * (4 * PAR_SPRITE_W) + dx4);                // alt:330-332, in bytes
             int sid = 0;
-            if (IDS && a.sprite_ids) sid = ld_uniform(a.sprite_ids + (int)x[6]);          // alt:321-322
-            const char* dtab = (!IDS || sid == 0) ? depth0 : reinterpret_cast<const char*>(a.sprites[sid].depth);
-            // (every lane loads: a lane outside the rectangle reads texel 0 and its result is not used)
-            const int d = *reinterpret_cast<const int32_t*>(dtab + (lane_of(in) ? t4 : 0u));
+            if (has_ids) {                                                                 // alt:321-322
+                sid = ld_uniform(a.sprite_ids + (int)x[6]);
+                dtab = depth_table(a.sprites, sid);
+            }
+            // (every lane loads: outside the rectangle t4 is any number; past the table the load returns 0)
+            const int d = __builtin_amdgcn_raw_buffer_load_b32(dtab, (int)t4, 0, 0);
             const int depth = (int)x[4] + min(0, (int)x[3] + wj) - d;                      // alt:336-341
             const lanemask better = __ballot(closest < depth) & in;                        // alt:344-346
             if (lane_of(better)) {
@@ -1654,8 +1810,8 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
             hit_bin |= better;                                                             // alt:365
         }
         // (a pixel was hit exactly when `closest` moved: the comparison alt:344 is strict)
-        lanemask hit = __ballot(closest != INT_MIN);
-        if (fl & (1u << 26)) hit = 0;  // bit 26: ablation (timing experiments only), no shading
+        lanemask hit = __ballot(closest != INT_MIN) & valid;
+        if (DBG && (fl & (1u << 26))) hit = 0;  // bit 26: ablation (timing experiments only), no shading
         if (!hit) continue;
 
         // ---- shading, alt:704-758 ------------------------------------------------------------------------------
@@ -1687,8 +1843,13 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
         const float fox = (float)(int)(int16_t)col, foy = (float)(int)(int16_t)p_y, foz = (float)(int)(int16_t)p_z;  // alt:720-722
         lanemask lit = hit;
         lanemask pending = hit;
-        const lanemask not_finite = (__ballot(!__builtin_isfinite(inv_x)) | __ballot(!__builtin_isfinite(inv_y)) |
-                                     __ballot(!__builtin_isfinite(inv_z))) & hit;
+        // What a group's inverse directions have in common picks its loop (walk_list_lit's SIGNS). Per lane: the sign
+        // bits of the three inverses, or 9 when one of them is not finite (their product is finite exactly when all
+        // three are: each is 1 / n with |n| <= 1, so none is below 1 in magnitude and the product cannot overflow).
+        const float inv_prod = inv_x * inv_y * inv_z;
+        int sign_code = (int)((__float_as_uint(inv_x) >> 31) | ((__float_as_uint(inv_y) >> 31) << 1) |
+                              ((__float_as_uint(inv_z) >> 31) << 2));
+        sign_code = __builtin_isfinite(inv_prod) ? sign_code : 9;
         while (pending) {
             const int s_bin = __builtin_amdgcn_readlane(sz, __builtin_ctzll(pending));
             const lanemask grp = __ballot(sz == s_bin) & pending;
@@ -1700,6 +1861,8 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
                 woff = (int)(wd & 0xFFFFu);
                 wcnt = (int)(int16_t)(wd >> 16);  // -1: the walk was too long to record
             }
+            if (wcnt == 0) continue;  // nothing on the way to the light
+            lanemask alive = grp;
             if (wcnt < 0) {
                 // a start bin that holds no primitive (negative world z, sprite depths outside the box) or whose walk
                 // was too long to record: trace_hash_for_light as written, per lane
@@ -1708,34 +1871,28 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
                     l = lane_shadow_walk(g, a.count, a.slots, bx, by, s_bin, dyn, w_ent, (int)(int16_t)col,
                                          (int)(int16_t)p_y, (int)(int16_t)p_z, inv_x, inv_y, inv_z);
                 }
-                lit &= ~(__ballot(!l) & grp);
-                continue;
-            }
-            const par_walkrec* wr = walk + woff;
-            for (int r = 0; r < wcnt; r++) {
-                const u32x8 w = ld_uniform(reinterpret_cast<const u32x8*>(wr + r));
-                const v2f rx = {__uint_as_float(w[0]), __uint_as_float(w[1])};
-                const v2f ry = {__uint_as_float(w[2]), __uint_as_float(w[3])};
-                const v2f rz = {__uint_as_float(w[4]), __uint_as_float(w[5])};
-                const v2f tx = (rx - fox) * inv_x, ty2 = (ry - foy) * inv_y, tz = (rz - foz) * inv_z;  // alt:49-72
-                lanemask occl;
-                if (!not_finite) {
-                    // no NaN can arise (slab_hit): the mathematical min / max, by the hardware's instructions
-                    const float tmin = hw_max3(hw_min(tx.x, tx.y), hw_min(ty2.x, ty2.y), hw_min(tz.x, tz.y));
-                    const float tmax = hw_min3(hw_max(tx.x, tx.y), hw_max(ty2.x, ty2.y), hw_max(tz.x, tz.y));
-                    occl = __ballot(tmax >= tmin);
-                } else {  // (an axis-parallel light direction, 1 / 0, takes the reference's own sequence, alt:55-82)
-                    float tmin = std_min(tx.x, tx.y);
-                    float tmax = std_max(tx.x, tx.y);
-                    tmin = std_max(tmin, std_min(ty2.x, ty2.y));
-                    tmax = std_min(tmax, std_max(ty2.x, ty2.y));
-                    tmin = std_max(tmin, std_min(tz.x, tz.y));
-                    tmax = std_min(tmax, std_max(tz.x, tz.y));
-                    occl = __ballot(tmax >= tmin);
+                alive = __ballot(l) & grp;
+            } else {
+                // what the group's inverse directions have in common picks the loop (wave-uniform); every lane
+                // computes (uniform control flow: the loop counter stays a scalar), the group's lanes count
+                const par_walkrec* wr = walk + woff;
+                int signs = __builtin_amdgcn_readlane(sign_code, __builtin_ctzll(grp));
+                const lanemask same = __ballot(sign_code == signs) & grp;
+                if (same != grp) signs = (__ballot(sign_code == 9) & grp) ? 9 : 8;
+                switch (signs) {
+                    case 0: alive = walk_list_lit<0>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 1: alive = walk_list_lit<1>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 2: alive = walk_list_lit<2>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 3: alive = walk_list_lit<3>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 4: alive = walk_list_lit<4>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 5: alive = walk_list_lit<5>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 6: alive = walk_list_lit<6>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 7: alive = walk_list_lit<7>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    case 8: alive = walk_list_lit<8>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
+                    default: alive = walk_list_lit<9>(wr, wcnt, grp, fox, foy, foz, inv_x, inv_y, inv_z, w_ent); break;
                 }
-                lit &= ~(occl & __ballot((int)w[6] != w_ent) & grp);                        // alt:484-491
-                if ((lit & grp) == 0) break;
             }
+            lit &= ~(grp & ~alive);
         }
         // ---- quantise + store, alt:735, 757-758 ----------------------------------------------------------------
         if (DBG && (fl & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
@@ -1767,14 +1924,20 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
     }
 }
 
-// Wavefront `w` of `n_waves` (a multiple of PAR_ITEM_SHARDS): items w / shards, + n_waves / shards, ... of shard
-// w mod shards. The launch offers one wavefront per item of the host's bound, so the loop normally runs once.
+// Wavefront `w` of `n_waves` (a multiple of PAR_ITEM_SHARDS * PAR_WAVE_NW): the PAR_WAVE_NW wavefronts of a
+// workgroup take CONSECUTIVE items of one shard -- a column's items follow each other in its shard, so the
+// wavefronts that share a CU's scalar cache and L1 mostly read the same column record at the same time (with each
+// wavefront on a shard of its own a third of the scalar loads of a dense frame missed: 24 columns' records per CU
+// against 16 KB) -- workgroup v takes shard v mod shards, there the items (v / shards) * NW + its wavefront's
+// number, then on by n_waves / shards. The launch offers one wavefront per item of the host's bound (or per few),
+// so the loop runs once or a few times.
 template <bool DBG, bool IDS, bool FULL>
 __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
     const int lane = (int)threadIdx.x & 63;
-    const int shard = w & (PAR_ITEM_SHARDS - 1);
+    const int wg = w / PAR_WAVE_NW;
+    const int shard = wg & (PAR_ITEM_SHARDS - 1);
     const par_item* list = g.items + (size_t)shard * g.item_capacity;
-    const int first = w >> PAR_ITEM_SHARD_BITS;
+    const int first = (wg >> PAR_ITEM_SHARD_BITS) * PAR_WAVE_NW + (w % PAR_WAVE_NW);
     // the first item is fetched beside the counter (the list is allocated whatever the counter says)
     u32x8 it = item_fetch(list + min(first, g.item_capacity - 1));
     const int n = min(ld_uniform(g.item_counters + shard * PAR_ITEM_COUNTER_STRIDE), g.item_capacity);
@@ -2113,7 +2276,7 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
 // One wavefront per work item of the host's bound, or per few of them (rounded up to whole workgroups and to a
 // multiple of the shard count, which render_items' item-to-wavefront mapping needs).
 static int64_t item_workgroups(int64_t item_bound) {
-    const int64_t unit = PAR_ITEM_SHARDS > PAR_WAVE_NW ? PAR_ITEM_SHARDS : PAR_WAVE_NW;
+    const int64_t unit = (int64_t)PAR_ITEM_SHARDS * PAR_WAVE_NW;
     // Frames with very many items (dense scenes: 260 000 at 4096^2) are rendered by wavefronts that take several items
     // one after the other: launching a wavefront costs the chip more than its loop's extra iteration (full floor:
     // 382 us with one item per wavefront, 353 with 8, 347 with 16, 345 with 32), while a frame with few items needs
