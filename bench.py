@@ -109,7 +109,7 @@ def time_blocks(run_block, steps, blocks, barrier, reduce_max):
     return out
 
 
-def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, depth, steps):
+def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, depth, steps, counters_key=None):
     """An extra workload beside the headline (same code path, same harness): rate with `depth` frames in flight, one
     frame at a time, and the kernel groups of one frame timed apart."""
     import torch
@@ -146,6 +146,16 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
                 parts["fill_kernel"].append(st.ms_fill)
                 parts["render_items_kernel"].append(st.ms_render)
                 parts["render_overflow_kernel"].append(st.ms_overflow)
+        launched = [[] for _ in range(4)]
+        for i in range(13):
+            st = r.render_device(ptrs, stream=stream, timed=True, flags=par.RENDER_TIMED_AS_LAUNCHED)
+            if i >= 3:
+                for k in range(4):
+                    launched[k].append(st.ms_launch[k])
+        launched = [float(np.mean(v)) for v in launched]
+        clock_ghz = measured_clock_ghz(pipe, depth)
+        counters, counters_from = load_counters(counters_key) if counters_key else ({}, None)
+        render_issue = issue_fractions(counters.get("render_items_kernel"), launched[2], clock_ghz)
         stats = r.stats()
         full = r.render(("palidx",))
         covered = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
@@ -155,11 +165,80 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
             "hbm_frac": round(5.0 * w * h / (per * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "one_frame_at_a_time_ms": round(alone, 5),
             "kernels_ms_one_at_a_time": {k: round(float(np.mean(v)), 5) for k, v in parts.items()},
+            "launches_ms_as_launched": dict(zip(launch_names(len(aabbs)), [round(v, 5) for v in launched])),
+            "render_items_kernel": dict({"avg_ms": round(launched[2], 5), "clock_ghz": clock_ghz,
+                                         "counters_from": counters_from,
+                                         "hbm_frac": round(5.0 * covered / (launched[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                         if launched[2] > 0 else None}, **render_issue),
             "covered_pixels": covered, "pixels": w * h, "entities": int(stats.entities),
             "occupied_columns": int(stats.occupied_columns), "overflow_columns": int(stats.overflow_columns),
         }
     finally:
         pipe.close()
+
+
+def launch_names(n_prims):
+    """The launches of a production frame in order (small scenes build the hash in one launch)."""
+    build = "build_fill_kernel" if n_prims <= 16384 else "insert_fill_kernel+resolve_fill_kernel"
+    return [build, "columns_fill_kernel", "render_items_kernel", "render_overflow_kernel"]
+
+
+def fill_shares():
+    """What the library's fill plan gives the hash-build launch and the column launch (par_plan_fill)."""
+    pct = int(os.environ.get("PAR_TUNE_FILL_BUILD_PCT", "40"))
+    pct = min(100, max(0, pct))
+    return pct / 100.0, 1.0 - pct / 100.0
+
+
+def load_counters(workload):
+    """Wave-instruction counts per launch from the round's rocprofv3 passes (tools/profile_round.sh), with the commit
+    they were taken at."""
+    path = os.path.join(ROOT, "profiles", "sq_counters.json")
+    if not os.path.exists(path):
+        return {}, None
+    with open(path) as f:
+        j = json.load(f)
+    return j.get(workload, {}), j.get("collected")
+
+
+def load_traffic():
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(path):
+        return {}, None
+    with open(path) as f:
+        j = json.load(f)
+    return j, j.get("collected")
+
+
+def issue_fractions(counters, ms, clock_ghz):
+    """Share of the chip's vector / scalar issue slots a launch uses: wave-instructions x 4 cycles over 1024 SIMDs."""
+    if not counters or not clock_ghz or ms <= 0.0:
+        return {}
+    cycles = 1024.0 * clock_ghz * 1e9 * ms * 1e-3
+    return {"valu_wave_instructions": int(counters.get("SQ_INSTS_VALU", 0)),
+            "salu_wave_instructions": int(counters.get("SQ_INSTS_SALU", 0)),
+            "valu_frac": round(counters.get("SQ_INSTS_VALU", 0) * 4.0 / cycles, 4),
+            "salu_frac": round(counters.get("SQ_INSTS_SALU", 0) * 4.0 / cycles, 4)}
+
+
+def measured_clock_ghz(pipe, depth):
+    """Shader clock while the render kernel runs: its workgroups' s_memtime spans over their 100 MHz wall-clock spans
+    (debug time stamps of frames rendered with flag bit 29; median over workgroups)."""
+    import ctypes as C
+    pipe.submit_many(0, depth, 1 << 29)
+    pipe.synchronize()
+    rows, wgs = 6, 8192
+    buf = np.zeros(rows * wgs * 8, dtype=np.uint64)
+    par = importlib.import_module("pixel-art-raytracer_amd")
+    rc = par.lib().par_debug_read_stamps(pipe.slots[0].renderer._ctx, buf.ctypes.data_as(C.c_void_p), buf.size)
+    if rc != 0:
+        return None
+    st = buf.reshape(rows, wgs, 8)[3]
+    live = (st[:, 0] > 0) & (st[:, 7] > st[:, 0]) & (st[:, 5] > 0)
+    if not live.any():
+        return None
+    ghz = st[live, 5].astype(np.float64) / ((st[live, 7] - st[live, 0]).astype(np.float64) * 10.0)
+    return round(float(np.median(ghz)), 3)
 
 
 def main():
@@ -310,6 +389,9 @@ def main():
     # timed region: BLOCKS blocks of exactly K steps
     per_step = time_blocks(run_block, args.steps, max(1, args.blocks), barrier, reduce_max)
     ms_per_step = statistics.median(per_step)
+    # no kernel flagged a failure in any frame of the timed region (the flag is sticky; stats() raises PAR_ERR_DEVICE)
+    for s_ in pipe.slots:
+        s_.renderer.stats()
 
     # the frame's kernels while the timed configuration runs: workgroup time stamps of `depth` frames in mid-flight
     kernels_pipelined = None
@@ -413,44 +495,67 @@ def main():
             ms["render"].append(st.ms_render)
             ms["overflow"].append(st.ms_overflow)
         avg = {k: float(np.mean(v)) for k, v in ms.items()}
+        # ... and the launches of a PRODUCTION frame (the fill riding with the first two), one frame at a time
+        names = launch_names(N_PRIMS)
+        for _ in range(5):
+            r.render_device(ptrs, stream=stream, timed=True, flags=par.RENDER_TIMED_AS_LAUNCHED)
+        launched = [[] for _ in range(4)]
+        for _ in range(30):
+            st = r.render_device(ptrs, stream=stream, timed=True, flags=par.RENDER_TIMED_AS_LAUNCHED)
+            for i in range(4):
+                launched[i].append(st.ms_launch[i])
+        launched = [float(np.mean(v)) for v in launched]
         ncols = int(r.stats().occupied_columns)
         gx, gy, gz = params.grid_dims()
-        # Algorithmic bytes: 2.5 B per nominal ray (SURVEY §8d) = 5 B per pixel (4 B RGBA8 + 1 B palette index; two
-        # rays per pixel). The fill writes every pixel of the frame once (5 B x W x H); render_items_kernel then
-        # writes the pixels primitives cover (5 B x covered pixels) - the only bytes that kernel has to move.
+        # Algorithmic bytes: 2.5 B per nominal ray (SURVEY 8d) = 5 B per pixel (4 B RGBA8 + 1 B palette index; two
+        # rays per pixel). The fill writes every pixel of the frame once (5 B x W x H), shared between the first two
+        # launches as the library's plan says (40 % / 60 %); render_items_kernel then writes the pixels primitives
+        # cover (5 B x covered pixels) - the only bytes that kernel has to move.
         bytes_frame = 2.5 * 2.0 * W * H
         bytes_render = 5.0 * hit_pixels
-        kernels = {"render_items_kernel": (avg["render"], bytes_render), "fill_kernel": (avg["fill"], bytes_frame)}
-        dominant = "render_items_kernel"  # of the three launches of a production frame, the longest
-        dom_ms, dom_bytes = kernels[dominant]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        traffic_from = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            traffic = tj.get(dominant + "_hbm_bytes_per_launch")
-            traffic_from = tj.get("collected")
+        fill_share = fill_shares()
+        algorithmic = [bytes_frame * fill_share[0], bytes_frame * fill_share[1], bytes_render, 0.0]
+        clock_ghz = measured_clock_ghz(pipe, depth)
+        counters, counters_from = load_counters("headline")
+        traffic_json, traffic_from = load_traffic()
+        launches = []
+        for i, name in enumerate(names):
+            if launched[i] <= 0.0 or (i == 3 and algorithmic[i] == 0.0 and launched[i] < 1e-3):
+                continue
+            e = {"kernel": name, "avg_ms": round(launched[i], 5), "algorithmic_bytes": int(algorithmic[i]),
+                 "hbm_gbps": round(algorithmic[i] / (launched[i] * 1e-3) / 1e9, 1),
+                 "hbm_frac": round(algorithmic[i] / (launched[i] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                 "traffic": traffic_json.get(name + "_hbm_bytes_per_launch")}
+            e.update(issue_fractions(counters.get(name), launched[i], clock_ghz))
+            launches.append(e)
+        dom = max(launches, key=lambda e: e["avg_ms"])  # the longest launch of the frame, as measured in this run
+        issue = max(dom.get("valu_frac") or 0.0, dom.get("salu_frac") or 0.0)
         serial_ms = avg["bin"] + avg["fill"] + avg["render"] + avg["overflow"]
         out["roofline"] = {
-            "kernel": dominant, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-            "traffic_from": traffic_from or "profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                            "of this round; not measured in this run)",
-            "algorithmic_bytes_per_launch": int(dom_bytes), "avg_kernel_ms": round(dom_ms, 5),
-            "timing": "hipEvent pairs on the launch stream around each kernel (kernels launched apart and one frame at "
-                      "a time for this measurement), mean of 30 frames; the bracket includes the two launch boundaries, "
-                      "about 2 us more than the dispatch duration rocprofv3 reports for the same kernel "
-                      "(profiles/*_one_frame_at_a_time_*)",
-            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index); render_items_kernel writes "
-                        f"the {hit_pixels} covered pixels, the fill all {W * H}",
-            "note": "render_items_kernel is latency bound (a chain of dependent loads and dependent arithmetic per "
-                    "64-pixel work item), not bandwidth bound (DESIGN.md section 5); only the fill is",
-            "kernels_ms": {"hash_build+columns (bare, no fill riding)": round(avg["bin"], 5),
-                           "fill_kernel (on its own)": round(avg["fill"], 5),
-                           "render_items_kernel": round(avg["render"], 5),
-                           "render_overflow_kernel": round(avg["overflow"], 5)},
+            "kernel": dom["kernel"],
+            "bound": "hbm" if dom["hbm_frac"] >= issue else "valu",
+            "achieved": dom["hbm_gbps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": dom["hbm_frac"],
+            "traffic": dom["traffic"], "traffic_from": traffic_from,
+            "valu_frac": dom.get("valu_frac"), "salu_frac": dom.get("salu_frac"),
+            "counters_from": counters_from, "clock_ghz": clock_ghz,
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes"], "avg_kernel_ms": dom["avg_ms"],
+            "launches": launches,
+            "timing": "hipEvent pairs on the launch stream around each launch of a production frame (the fill riding "
+                      "with the first two launches, PAR_RENDER_TIMED_AS_LAUNCHED), one frame at a time, mean of 30 "
+                      "frames; a bracket includes the launch boundary, about 2 us more than the dispatch duration "
+                      "rocprofv3 reports for the same kernel (profiles/*_one_frame_at_a_time_*)",
+            "per_unit": "2.5 B per nominal ray = 5 B per pixel (RGBA8 + palette index): the two fill-carrying launches "
+                        f"write all {W * H} pixels between them ({fill_share[0]:.0%} / {fill_share[1]:.0%}), "
+                        f"render_items_kernel the {hit_pixels} covered ones",
+            "issue_roofline": "valu_frac / salu_frac = wave-instructions of the launch (rocprofv3 SQ_INSTS_VALU / "
+                              "SQ_INSTS_SALU of the commit named in counters_from) x 4 cycles / (1024 SIMDs x the "
+                              "clock measured in this run x the launch's duration): the share of the chip's vector / "
+                              "scalar issue slots the launch uses; tools/issuebench.hip has the per-instruction prices "
+                              "behind the 4 cycles (profiles/r03_issue_costs.json)",
+            "kernels_ms_apart": {"hash_build+columns (bare, no fill riding)": round(avg["bin"], 5),
+                                 "fill_kernel (on its own)": round(avg["fill"], 5),
+                                 "render_items_kernel": round(avg["render"], 5),
+                                 "render_overflow_kernel": round(avg["overflow"], 5)},
             "fill_kernel": {"achieved": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9, 1),
                             "frac": round(bytes_frame / (avg["fill"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "whole_frame": {"achieved": round(bytes_frame / (ms_per_step * 1e-3) / 1e9, 1),
@@ -484,12 +589,12 @@ def main():
             floor = T.make_aabbs([(i * 20, 0, j * 20, 20, 20, 20) for i in range(W // 20) for j in range(L // 20)])
             out["dense"] = side_scene(par, pipeline, T, f"{W}x{H} full floor of {len(floor)} tiles under the same light: "
                                       "every pixel covered, every shadow ray traced", params, floor, light, sprite,
-                                      local_rank, depth, 60)
+                                      local_rank, depth, 60, counters_key="floor")
             p0 = T.default_params()
             out["default_scene"] = side_scene(par, pipeline, T, "480x320x320, the reference's graybox world "
                                               "(alt:517-599), light (480,160,80): the reference's own workload",
                                               p0, par.scene_graybox(), T.make_light(480, 160, 80), sprite, local_rank,
-                                              depth, 2000)
+                                              depth, 2000, counters_key="graybox")
         if not args.no_cpu_baseline:
             rows = (3 * H // 8, 5 * H // 8)
             out["cpu_baseline"], out["verified_vs_oracle_rows"] = cpu_baseline(params, aabbs, light, sprite, rows,

@@ -33,7 +33,11 @@ typedef enum par_status {
     PAR_ERR_UNSUPPORTED = 5, /* grid dimension or bin size outside what the kernels are built for */
     PAR_ERR_EXTENT = 6,      /* an AABB extent the 20x40 sprite cannot express (reference UB: alt:330, SURVEY a-3b) */
     PAR_ERR_SPRITE_ID = 7,   /* sprite id or sprite palette index out of range */
-    PAR_ERR_NOT_READY = 8    /* render before sprites / entities / light were set */
+    PAR_ERR_NOT_READY = 8,   /* render before sprites / entities / light were set */
+    PAR_ERR_DEVICE = 9       /* a kernel reported a failure since the flag was last read (the hash build's barrier timed
+                              * out, or a column overflowed its record in a frame that was sized for none to): a frame
+                              * rendered since then is NOT valid. Reported once, by the first call that looks: par_render,
+                              * par_render_rows, par_render_device_timed, par_get_stats */
 } par_status;
 
 /* Render flags. */
@@ -47,7 +51,10 @@ enum {
     /* This frame is one of several in flight on the device (a swap chain, par_render_device_slots): favour the
      * device's throughput over the frame's own latency (one wavefront per screen column builds its record and does
      * all its shadow walks, instead of two sharing the walks). Same pixels either way. */
-    PAR_RENDER_PIPELINED = 1u << 2
+    PAR_RENDER_PIPELINED = 1u << 2,
+    /* par_render_device_timed only: time the frame's launches AS A PRODUCTION FRAME MAKES THEM (the background fill
+     * riding with the hash-build and column launches) into par_frame_stats.ms_launch, instead of the kernels apart. */
+    PAR_RENDER_TIMED_AS_LAUNCHED = 1u << 3
     /* Bit 22 (tests): no self-contained work items, every column is rendered from its record; same pixels.
      * Bit 23 (tests): build the spatial hash with two launches even where one would do; same pixels.
      * Bits 24-28 switch parts of the frame OFF for timing experiments (tools/ablate.py, tools/overlap.py): the output
@@ -66,7 +73,8 @@ typedef struct par_outputs {
 
 typedef struct par_frame_stats {
     int64_t entities;        /* entities uploaded */
-    int64_t bin_insertions;  /* (entity, bin) pairs inserted this frame (alt:243-267 iterations) */
+    int64_t bin_insertions;  /* (entity, bin) pairs the device inserted in the last frame (alt:243-267 iterations; the
+                              * insert kernel's own node count) */
     int64_t shadow_rays;     /* shadow rays traced (only with PAR_RENDER_COUNT_RAYS), else -1 */
     int64_t occupied_columns; /* screen columns (bin footprints) in the rendered rows that show a primitive */
     int64_t overflow_columns; /* ... of which did not fit a column record (rendered straight from the hash) */
@@ -74,6 +82,10 @@ typedef struct par_frame_stats {
     float ms_fill;           /* device time of the background fill kernel of the last timed render, else -1 */
     float ms_render;         /* device time of the render kernel (render_wave_kernel) of the last timed render, else -1 */
     float ms_overflow;       /* device time of the overflow-column kernel of the last timed render, else -1 */
+    float ms_launch[4];      /* PAR_RENDER_TIMED_AS_LAUNCHED: device time of the frame's launches as a production frame
+                              * makes them: [0] hash build (+ its share of the fill), [1] column records (+ the rest of the
+                              * fill), [2] render (work items), [3] overflow list (0 when the frame has no such launch);
+                              * else -1 */
 } par_frame_stats;
 
 const char* par_status_string(int status);
@@ -125,7 +137,9 @@ int par_render_device(par_context* ctx, void* stream, int row_begin, int row_end
                       unsigned flags);
 /* The render loop of a swap chain in one call: frames first_frame .. first_frame + n_frames - 1, frame i on slot
  * i % n_slots (its context, its stream, its device outputs), enqueued back to back without a host wait. Each slot is
- * a context of its own; all of them render the same rows. */
+ * a context of its own; all of them render the same rows. Like par_render_device it never waits for the device, so it
+ * cannot see a kernel's failure flag (PAR_ERR_DEVICE): the caller polls par_get_stats on each slot's context when it
+ * next waits for that slot anyway (the flag is sticky until read). */
 int par_render_device_slots(par_context* const* ctxs, void* const* streams, const par_outputs* device_outs,
                             int n_slots, int row_begin, int row_end, int first_frame, int n_frames, unsigned flags);
 /* As par_render_device, bracketing the kernel groups with HIP events on `stream`; blocks until the frame is done
@@ -146,7 +160,8 @@ int par_graph_launch(par_context* ctx, void* stream);
  * plane is the caller's to read; this helper renders just that pixel's row. */
 int par_pick(par_context* ctx, int x, int y, par_pixel* out);
 
-/* Statistics of the last render (blocks until it finished). */
+/* Statistics of the last render (blocks until it finished). PAR_ERR_DEVICE when a kernel flagged a failure since the
+ * flag was last read. */
 int par_get_stats(par_context* ctx, par_frame_stats* stats);
 
 /* Read back the spatial hash of the last render in the reference's layout (`count[G]`, `map[G*8]`,

@@ -24,10 +24,11 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpar_raytracer.so")
 
 PAR_OK = 0
 STATUS_NAMES = {0: "PAR_OK", 1: "PAR_ERR_INVALID_ARG", 2: "PAR_ERR_NO_DEVICE", 3: "PAR_ERR_HIP", 4: "PAR_ERR_OOM",
-                5: "PAR_ERR_UNSUPPORTED", 6: "PAR_ERR_EXTENT", 7: "PAR_ERR_SPRITE_ID", 8: "PAR_ERR_NOT_READY"}
+                5: "PAR_ERR_UNSUPPORTED", 6: "PAR_ERR_EXTENT", 7: "PAR_ERR_SPRITE_ID", 8: "PAR_ERR_NOT_READY", 9: "PAR_ERR_DEVICE"}
 RENDER_TRACE_BACKGROUND = 1 << 0
 RENDER_COUNT_RAYS = 1 << 1
 RENDER_PIPELINED = 1 << 2
+RENDER_TIMED_AS_LAUNCHED = 1 << 3
 
 # every symbol include/par_raytracer.h declares
 ABI_SYMBOLS = (

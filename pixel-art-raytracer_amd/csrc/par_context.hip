@@ -21,6 +21,8 @@ struct par_footprint {
     int16_t x0 = 0, x1 = 0, y0 = 0, y1 = 0;
     int32_t nz = 0;
     int32_t items = 0;  // render work items (64-pixel chunks) the entity can cause, see footprint_of
+    int16_t px = 0, ex = 0;     // its sprite rectangle on screen (alt:310-317): columns [px, px + ex),
+    int32_t row0 = 0, rh = 0;   // rows [row0, row0 + rh) = H - (py + ey + pz + ez) .. H - (py + pz)
     int32_t cols() const { return (x1 - x0) * (y1 - y0); }
     int64_t pairs() const { return (int64_t)cols() * nz; }  // (entity, bin) insertions, alt:243-267
 };
@@ -39,6 +41,11 @@ struct par_context {
     int64_t total_items = 0;       // >= the render work items (64-pixel chunks) of the frame, see footprint_of
     std::vector<int32_t> h_colpairs;  // (entity, bin) pairs per screen column (>= its occupied bins, >= its entries)
     int64_t cols_over = 0;            // columns with more pairs than a column record is sure to hold
+    // 64-pixel chunks of the entities' sprite rectangles per screen column (what the column kernel adds up, over the
+    // visible entries only, to choose between visiting a column entry by entry and as a whole tile), and the columns
+    // where that reaches the tile's own chunks: only those can be visited as tiles
+    std::vector<int32_t> h_colchunks;
+    int64_t cols_tileable = 0;
     int n_entities = 0, n_sprites = 0, max_sprite_id = 0;
     bool have_light = false, have_entities = false;
     par_light light{};
@@ -83,7 +90,7 @@ struct par_context {
     int64_t graph_pair_bound = 0;  // (entity, bin) pairs a captured graph's launch grids can take
     int64_t graph_item_bound = 0;  // ... and render work items
 
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     par_frame_stats stats{};
     unsigned last_flags = 0;
     std::string err;
@@ -152,6 +159,9 @@ par_footprint footprint_of(const par_context* c, const par_aabb& a) {
     f.x0 = (int16_t)x0; f.x1 = (int16_t)x1; f.y0 = (int16_t)y0; f.y1 = (int16_t)y1;
     f.nz = z1 - z0;
     f.items = (int32_t)((int)a.ex * ((int)a.ey + (int)a.ez) / 64 + f.cols());
+    f.px = a.px; f.ex = a.ex;
+    f.row0 = H - ((int)a.py + a.ey + a.pz + a.ez);
+    f.rh = (int)a.ey + (int)a.ez;
     return f;
 }
 
@@ -160,12 +170,24 @@ par_footprint footprint_of(const par_context* c, const par_aabb& a) {
 // launch for the overflow list.
 void col_hist(par_context* c, const par_footprint& f, int sign) {
     constexpr int kSure = PAR_COL_NB < PAR_COL_ENT ? PAR_COL_NB : PAR_COL_ENT;
+    const int W = c->params.width, H = c->params.height, B = c->params.bin_size;
     for (int x = f.x0; x < f.x1; x++) {
+        const int cx0 = x * B, tw = std::min(B, W - cx0);
+        const int w = std::min(f.px + f.ex, cx0 + tw) - std::max((int)f.px, cx0);
         for (int y = f.y0; y < f.y1; y++) {
             int32_t& n = c->h_colpairs[(size_t)x * c->gy + y];
             const bool was = n > kSure;
             n += sign * f.nz;
             c->cols_over += (int)(n > kSure) - (int)was;
+            const int ry0 = y * B, th = std::min(B, H - ry0);
+            const int h = std::min(f.row0 + f.rh, ry0 + th) - std::max(f.row0, ry0);
+            if (w > 0 && h > 0) {
+                const int tile_chunks = (tw * th + 63) / 64;
+                int32_t& k = c->h_colchunks[(size_t)x * c->gy + y];
+                const bool could = k >= tile_chunks;
+                k += sign * ((w * h + 63) / 64);
+                c->cols_tileable += (int)(k >= tile_chunks) - (int)could;
+            }
         }
     }
 }
@@ -244,12 +266,12 @@ int ensure_items(par_context* ctx, int64_t items, int64_t cols) {
     if (need <= ctx->grid.item_capacity) return PAR_OK;
     if (ctx->graph_exec[0]) return fail(ctx, PAR_ERR_UNSUPPORTED, "work-item list would grow under a captured graph; capture again");
     const int64_t cap = std::max<int64_t>(need + need / 2, 1 << 10);
-    if (cap > 0x3FFFFFFF / PAR_ITEM_SHARDS) return fail(ctx, PAR_ERR_UNSUPPORTED, "too many render work items");
+    if (cap > 0x3FFFFFFF / (PAR_ITEM_LISTS * PAR_ITEM_SHARDS)) return fail(ctx, PAR_ERR_UNSUPPORTED, "too many render work items");
     PAR_HIP(hipDeviceSynchronize());
     if (ctx->grid.items) PAR_HIP(hipFree(ctx->grid.items));
     ctx->grid.items = nullptr;
     ctx->grid.item_capacity = 0;
-    PAR_HIP(hipMalloc(&ctx->grid.items, (size_t)cap * PAR_ITEM_SHARDS * sizeof(par_item)));
+    PAR_HIP(hipMalloc(&ctx->grid.items, (size_t)cap * PAR_ITEM_LISTS * PAR_ITEM_SHARDS * sizeof(par_item)));
     ctx->grid.item_capacity = (int32_t)cap;
     return PAR_OK;
 }
@@ -355,15 +377,22 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     a.ambient = c->params.ambient;
     a.background = c->params.background;
     a.flags = flags;
-    // Chunks per work item of a column visited as a whole tile: a frame with many chunks (a dense scene) lets a
-    // wavefront read what a column's chunks share once for several of them; a frame with few needs every wavefront it
-    // can get. PAR_TUNE_TILE_K overrides (tools).
+    // Columns are visited as whole tiles only in DENSE frames, which get a launch for the tile items: enough columns
+    // (a 64th of the grid, at least 16) whose entities' rectangles add up to the tile (the column kernel's own
+    // criterion, over the visible entries). A frame with fewer visits every column entry by entry (tile_k 0) and keeps
+    // its three launches. A captured graph serves later frames too: it always has the launch. Then: how many chunks
+    // per tile item -- a frame with many lets a wavefront read what a column's chunks share once for several of them,
+    // a frame with few needs every wavefront it can get. PAR_TUNE_TILE_K overrides (tools; 0 is "never").
     static const int tuned_k = [] {
         const char* e = std::getenv("PAR_TUNE_TILE_K");
-        const int v = e ? std::atoi(e) : 0;
-        return v < 0 ? 0 : (v > 64 ? 64 : v);
+        const int v = e ? std::atoi(e) : -1;
+        return v > 64 ? 64 : v;
     }();
-    a.tile_k = tuned_k > 0 ? tuned_k : (c->total_items >= 65536 ? 5 : (c->total_items >= 16384 ? 3 : (c->total_items >= 4096 ? 2 : 1)));
+    const int64_t grid_cols = (int64_t)c->gx * c->gy;
+    const bool dense_frame = dyn_from_device || c->cols_tileable >= std::max<int64_t>(16, grid_cols / 64);
+    a.tile_k = tuned_k >= 0 ? tuned_k
+                            : (!dense_frame ? 0 : (c->total_items >= 65536 ? 5 : (c->total_items >= 16384 ? 3 : (c->total_items >= 8192 ? 2 : 1))));
+    a.tile_k_magic = a.tile_k > 0 ? (uint32_t)(65536 / a.tile_k + 1) : 65537u;
     a.dyn = make_dyn(c, c->light);
     a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;
     a.count = c->grid.count[set];
@@ -386,7 +415,27 @@ par_bin_args make_bin_args(const par_context* c, int set, int row_begin, int row
     b.n = c->n_entities;
     b.set = set;
     b.aabbs = c->d_aabbs;
+    // tests: a build workgroup that never arrives at the one-launch hash build's barrier (PAR_ERR_DEVICE)
+    static const bool lose = [] { const char* e = std::getenv("PAR_TEST_LOSE_BUILD_WG"); return e && e[0] == '1'; }();
+    b.test_lose_wg = lose ? 1 : 0;
     return b;
+}
+
+// The kernels' sticky failure word (PAR_CNT_ERROR), read after a wait for the device: reported once (PAR_ERR_DEVICE)
+// and cleared. The caller has synchronised with the frames it is asking about.
+int check_device_error(par_context* ctx) {
+    int32_t word = 0;
+    PAR_HIP(hipMemcpy(&word, ctx->grid.counters + PAR_CNT_ERROR, sizeof(word), hipMemcpyDeviceToHost));
+    if (word == 0) return PAR_OK;
+    PAR_HIP(hipMemset(ctx->grid.counters + PAR_CNT_ERROR, 0, sizeof(word)));
+    std::string what;
+    if (word & PAR_DEVERR_BARRIER) {
+        what += "the hash build's barrier timed out (a build workgroup never arrived); ";
+    }
+    if (word & PAR_DEVERR_OVERFLOW) {
+        what += "a column overflowed its record in a frame enqueued without a launch for the overflow list; ";
+    }
+    return fail(ctx, PAR_ERR_DEVICE, what + "a frame rendered since the last check is not valid");
 }
 
 // Enqueue one frame (alt:690-760) on `stream` using grid set `set`.
@@ -412,7 +461,12 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
         PAR_HIP(hipStreamWaitEvent(stream, ctx->ev_update, 0));
     }
     const par_bin_args b = make_bin_args(ctx, set, row_begin, row_end, flags);
-    const par_render_args r = make_render_args(ctx, set, row_begin, row_end, outs, flags, graph_mode);
+    par_render_args r = make_render_args(ctx, set, row_begin, row_end, outs, flags, graph_mode);
+    // The overflow list is empty for sure while no column has more pairs than a record holds (a captured graph also
+    // serves later frames, whose columns nobody knows yet): then the frame has no launch for it, and the column
+    // kernel flags the frame should a column overflow all the same.
+    const bool may_overflow = graph_mode || ctx->cols_over > 0 || r.dense || (ev && !(flags & PAR_RENDER_TIMED_AS_LAUNCHED));
+    r.overflow_launched = may_overflow ? 1 : 0;
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
     }
@@ -422,7 +476,9 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // so that the event pairs bracket single ones).
     par_fill_plan plan;
     const bool no_fill = (flags & (1u << 28)) != 0;  // ablation (timing experiments only): no background fill
-    const bool ride = !ev && !no_fill && par_plan_fill(r, &plan);
+    // (a timed frame keeps its kernels apart unless it is asked to time the launches as a production frame makes them)
+    const bool apart = ev && !(flags & PAR_RENDER_TIMED_AS_LAUNCHED);
+    const bool ride = !apart && !no_fill && par_plan_fill(r, &plan);
     par_render_args rf = r;  // what rides along: the frame and palette-index planes
     rf.out.lit = nullptr;
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
@@ -431,7 +487,7 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // small scenes build the hash in one launch, large ones in two (timed runs keep the kernels apart)
     static const bool two_env = [] { const char* e = std::getenv("PAR_BUILD_TWO_LAUNCHES"); return e && e[0] == '1'; }();
     const bool two_launches = two_env || (flags & (1u << 23));  // bit 23 (tests): insert and resolve as two launches
-    hipError_t be = (ev || two_launches) ? hipErrorNotSupported
+    hipError_t be = (apart || two_launches) ? hipErrorNotSupported
                                          : par_launch_build(ctx->grid, b, pair_bound, &rf, ride ? &plan : nullptr, stream);
     if (be == hipErrorNotSupported) {
         PAR_HIP(par_launch_bin_insert(ctx->grid, b, &rf, ride ? &plan : nullptr, stream));
@@ -439,6 +495,7 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     } else if (be != hipSuccess) {
         return hip_fail(ctx, be, "par_launch_build");
     }
+    if (ev) PAR_HIP(hipEventRecord(ev[5], stream));  // (behind the hash build)
     // occupied columns <= the columns the entities reach one by one (<= their (entity, bin) pairs)
     const int64_t col_bound = graph_mode ? pair_bound : ctx->total_cols;
     if (ride) {
@@ -464,11 +521,8 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // work items <= what the entities can cause one by one, and <= every column of the rendered rows as a whole tile
     const int64_t item_cap_rows = max_items(ctx) / ctx->gy * (r.by_hi - r.by_lo + 1);
     const int64_t item_bound = std::min(graph_mode ? ctx->graph_item_bound : ctx->total_items, item_cap_rows);
-    // The overflow list is empty for sure while no column has more pairs than a record holds (a captured graph also
-    // serves later frames, whose columns nobody knows yet).
-    const bool may_overflow = graph_mode || ctx->cols_over > 0 || r.dense || ev;
     bool both = false;
-    if (!ev) {  // small frames: one launch for both render kernels
+    if (!apart) {  // small frames: one launch for both render kernels
         const hipError_t e = par_launch_render_both(ctx->grid, r, col_bound, item_bound, may_overflow, stream);
         if (e == hipSuccess) {
             both = true;
@@ -476,7 +530,10 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
             return hip_fail(ctx, e, "par_launch_render_both");
         }
     }
-    if (!both) PAR_HIP(par_launch_render(ctx->grid, r, item_bound, stream));
+    if (!both) {
+        PAR_HIP(par_launch_render(ctx->grid, r, item_bound, stream));
+        PAR_HIP(par_launch_render_tiles(ctx->grid, r, item_bound, stream));  // (dense frames only: r.tile_k > 0)
+    }
     if (ev) PAR_HIP(hipEventRecord(ev[4], stream));
     if (!both && may_overflow) PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
@@ -515,7 +572,7 @@ int render_to_host(par_context* ctx, int row_begin, int row_end, const par_outpu
         if (host[i]) PAR_HIP(hipMemcpyAsync(host[i], dev[i], n * kPlaneElem[i], hipMemcpyDeviceToHost, ctx->stream));
     }
     PAR_HIP(hipStreamSynchronize(ctx->stream));
-    return PAR_OK;
+    return check_device_error(ctx);
 }
 
 }  // namespace
@@ -563,6 +620,7 @@ static int par_create_impl(const par_params* params, int device, par_context** o
     ctx->grid.gx = gx; ctx->grid.gy = gy; ctx->grid.gz = gz; ctx->grid.volume = ctx->volume;
     ctx->stats.shadow_rays = -1; ctx->stats.ms_bin = -1.f; ctx->stats.ms_fill = -1.f; ctx->stats.ms_render = -1.f;
     ctx->stats.ms_overflow = -1.f;
+    for (float& v : ctx->stats.ms_launch) v = -1.f;
     auto bail = [&](hipError_t e) {
         int rc = e == hipErrorOutOfMemory ? PAR_ERR_OOM : PAR_ERR_HIP;
         par_destroy(ctx);
@@ -581,7 +639,7 @@ static int par_create_impl(const par_params* params, int device, par_context** o
     if ((e = hipMalloc(&ctx->grid.build_sync, 64 * sizeof(int32_t))) != hipSuccess) return bail(e);
     if ((e = hipMemset(ctx->grid.build_sync, 0, 64 * sizeof(int32_t))) != hipSuccess) return bail(e);
     {
-        const size_t bytes = (size_t)PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE * sizeof(int32_t);
+        const size_t bytes = (size_t)PAR_ITEM_LISTS * PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE * sizeof(int32_t);
         if ((e = hipMalloc(&ctx->grid.item_counters, bytes)) != hipSuccess) return bail(e);
         if ((e = hipMemset(ctx->grid.item_counters, 0, bytes)) != hipSuccess) return bail(e);
     }
@@ -601,7 +659,7 @@ static int par_create_impl(const par_params* params, int device, par_context** o
     if ((e = hipMalloc(&ctx->d_dyn, sizeof(par_frame_dyn))) != hipSuccess) return bail(e);
     if ((e = hipMemcpy(ctx->d_palette, p.palette, PAR_MAX_PALETTE * sizeof(par_color), hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if ((e = hipMemset(ctx->grid.slots, 0, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 6; i++) {
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return bail(e);
     }
     if (reset_grid(ctx) != PAR_OK) {
@@ -647,7 +705,7 @@ void par_destroy(par_context* ctx) {
         if (ctx->pin_dyn[s]) (void)hipHostFree(ctx->pin_dyn[s]);
         if (ctx->ev_graph[s]) (void)hipEventDestroy(ctx->ev_graph[s]);
     }
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 6; i++) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -738,6 +796,8 @@ static int par_set_entities_impl(par_context* ctx, const par_aabb* aabbs, const 
     ctx->h_aabbs.assign(aabbs, aabbs + n);
     ctx->h_colpairs.assign((size_t)ctx->gx * ctx->gy, 0);
     ctx->cols_over = 0;
+    ctx->h_colchunks.assign((size_t)ctx->gx * ctx->gy, 0);
+    ctx->cols_tileable = 0;
     for (int i = 0; i < n; i++) col_hist(ctx, fps[(size_t)i], +1);
     ctx->h_fp.swap(fps);
     ctx->total_pairs = total;
@@ -909,8 +969,15 @@ static int par_render_device_timed_impl(par_context* ctx, void* stream, int row_
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_fill, ctx->ev[1], ctx->ev[3]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[3], ctx->ev[4]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_overflow, ctx->ev[4], ctx->ev[2]));
+    for (float& v : ctx->stats.ms_launch) v = -1.f;
+    if (flags & PAR_RENDER_TIMED_AS_LAUNCHED) {
+        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[0], ctx->ev[0], ctx->ev[5]));
+        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[1], ctx->ev[5], ctx->ev[3]));
+        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[2], ctx->ev[3], ctx->ev[4]));
+        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[3], ctx->ev[4], ctx->ev[2]));
+    }
     if (stats) return par_get_stats(ctx, stats);
-    return PAR_OK;
+    return check_device_error(ctx);
 }
 
 static int par_graph_capture_impl(par_context* ctx, void* stream_v, int row_begin, int row_end, const par_outputs* device_out,
@@ -1045,18 +1112,19 @@ static int par_get_stats_impl(par_context* ctx, par_frame_stats* stats) {
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
     ctx->stats.entities = ctx->n_entities;
-    ctx->stats.bin_insertions = ctx->total_pairs;
     ctx->stats.shadow_rays = -1;
     {
-        int32_t nc[3] = {0, 0, 0};
-        static_assert(PAR_CNT_COLS == 0 && PAR_CNT_SLOW == 1 && PAR_CNT_ERROR == 2, "read together");
+        int32_t nc[2] = {0, 0};
+        static_assert(PAR_CNT_COLS == 0 && PAR_CNT_SLOW == 1, "read together");
         PAR_HIP(hipMemcpy(nc, ctx->grid.counters, sizeof(nc), hipMemcpyDeviceToHost));
         ctx->stats.occupied_columns = nc[0];
         ctx->stats.overflow_columns = nc[1];
-        if (nc[2] != 0) {
-            return fail(ctx, PAR_ERR_HIP, "the hash build's barrier timed out in the last frame (a build workgroup "
-                                          "never arrived): that frame is not valid");
-        }
+        // the insert kernel's own count of the last frame's (entity, bin) nodes (the next frame's resolve resets it)
+        int32_t nodes = 0;
+        PAR_HIP(hipMemcpy(&nodes, ctx->grid.node_counter + (ctx->set ^ 1), sizeof(nodes), hipMemcpyDeviceToHost));
+        ctx->stats.bin_insertions = nodes;
+        const int rc = check_device_error(ctx);
+        if (rc != PAR_OK) return rc;
     }
     if (ctx->last_flags & PAR_RENDER_COUNT_RAYS) {
         unsigned long long v = 0;

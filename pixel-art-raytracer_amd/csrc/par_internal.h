@@ -19,7 +19,7 @@ static_assert(sizeof(par_slot) == 16, "slot record must stay 16 bytes");
 
 constexpr int PAR_STAMP_SLOTS = 8;      // time stamps per workgroup in the debug stamp buffer
 constexpr int PAR_STAMP_WGS = 8192;     // workgroups per kernel that get a row in it
-constexpr int PAR_STAMP_ROWS = 5;       // kernels of a frame
+constexpr int PAR_STAMP_ROWS = 6;       // kernels of a frame (row 5: render_tiles_kernel)
 
 // Kernel geometry (see DESIGN.md "kernels").
 constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count (bin coordinates are kept in int16)
@@ -121,6 +121,7 @@ constexpr int PAR_WAVE_NW = 4;          // wavefronts per render workgroup
 // carries all the render kernel needs, which then never touches the column's record. The list is kept in PAR_ITEM_SHARDS shards (column index mod shards), each with its own counter, so
 // that the column workgroups' appends do not queue up on one address; wavefront w of the render launch takes items
 // w / shards, + waves / shards, ... of shard w mod shards.
+constexpr int PAR_ITEM_LISTS = 2;     // 0: entry passes (render_items_kernel), 1: whole-tile visits (render_tiles_kernel)
 constexpr int PAR_ITEM_SHARD_BITS = 6;
 constexpr int PAR_ITEM_SHARDS = 1 << PAR_ITEM_SHARD_BITS;
 constexpr int PAR_ITEM_COUNTER_STRIDE = 32;  // int32 words between two shard counters: one 128-byte line each
@@ -149,8 +150,9 @@ struct par_grid_dev {
     int32_t* col_list;        // [gx*gy] occupied columns (bx*gy + by) inside the rendered row range, unordered
     int32_t* counters;        // [PAR_CNT_TOTAL]: occupied columns, overflowed columns (reset by insert)
     par_colrec* colrec;       // [col_capacity] indexed like col_list
-    par_item* items;          // [PAR_ITEM_SHARDS * item_capacity] render work items: one 64-pixel chunk each
-    int32_t* item_counters;   // [PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE] items per shard (reset by insert)
+    par_item* items;          // [PAR_ITEM_LISTS * PAR_ITEM_SHARDS * item_capacity] render work items, list by list and
+                              // shard by shard: a 64-pixel chunk of an entry pass, or tile_k chunks of a tile visit
+    int32_t* item_counters;   // [PAR_ITEM_LISTS * PAR_ITEM_SHARDS * PAR_ITEM_COUNTER_STRIDE] items per shard (reset by insert)
     int32_t* build_sync;      // [64] barrier words of build_fill_kernel (arrived, left; they reset themselves)
     int32_t* slow_list;       // [gx*gy] indices into col_list of the columns that overflowed their record
     par_bgwalk* bgwalk;       // [gx] shadow walks of the background rays (traced only on request)
@@ -167,6 +169,7 @@ struct par_bin_args {
     int32_t set;             // which head/count/node/colflag set this frame uses
     int32_t by_lo, by_hi;    // bin rows [by_lo, by_hi] the render of this frame touches (column-list filter)
     uint32_t flags;          // render flags (bit 29: debug time stamps)
+    int32_t test_lose_wg;    // tests (PAR_TEST_LOSE_BUILD_WG=1): build workgroup 0 never arrives at the barrier
     const par_aabb* aabbs;
 };
 
@@ -181,7 +184,10 @@ struct par_render_args {
     float ambient;
     uint32_t background;           // gray level (alt:281)
     uint32_t flags;
-    int32_t tile_k;                // 64-pixel chunks per work item of a column visited as a whole tile (>= 1)
+    int32_t tile_k;                // 64-pixel chunks per work item of a column visited as a whole tile; 0: the frame
+                                   // has no launch for tile items (a sparse frame): every column is visited entry by entry
+    uint32_t tile_k_magic;         // floor(n / tile_k) == (n * magic) >> 16 for n < 1024
+    int32_t overflow_launched;     // 0: the frame has no launch for the overflow list (the host ruled it out)
     par_frame_dyn dyn;             // used when dyn_ptr == nullptr
     const par_frame_dyn* dyn_ptr;  // graph path
     const uint8_t* count;
@@ -194,7 +200,11 @@ struct par_render_args {
     unsigned long long* ray_counter;
 };
 
+// PAR_CNT_ERROR is STICKY: kernels only ever set bits in it (a frame's insert resets the other counters, not this
+// one); the host clears it when it reports it (PAR_ERR_DEVICE).
 enum { PAR_CNT_COLS = 0, PAR_CNT_SLOW = 1, PAR_CNT_ERROR = 2, PAR_CNT_TOTAL = 8 };
+enum { PAR_DEVERR_BARRIER = 1,    // build_fill_kernel: a build workgroup never arrived at the barrier (bounded wait)
+       PAR_DEVERR_OVERFLOW = 2 }; // a column went onto the overflow list in a frame without a launch for that list
 
 // The background fill split over the frame's first three launches: 512-pixel chunks [cut[i], cut[i+1]) go with
 // launch i (hash insert, hash resolve, column records).
@@ -226,7 +236,10 @@ hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipS
 // `item_bound`: an upper bound of the frame's work items (64-pixel chunks of the columns with a record).
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
                              hipStream_t stream);
-// Both render kernels in one launch for small frames (else hipErrorNotSupported, nothing launched).
+// The columns visited as whole tiles (a.tile_k > 0: a dense frame); `item_bound` as above (in chunks).
+hipError_t par_launch_render_tiles(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
+                                   hipStream_t stream);
+// All render kernels in one launch for small frames (else hipErrorNotSupported, nothing launched).
 hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                   int64_t item_bound, bool may_overflow, hipStream_t stream);
 // The columns that overflowed their record (every column when a.dense).

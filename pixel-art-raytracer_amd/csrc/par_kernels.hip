@@ -133,8 +133,8 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
     }
     // (resolve adds to the column counter with atomics: in the one-launch build a plain zero written here could
     // reach memory after them)
-    if (tid < PAR_CNT_TOTAL) st_shared<COH>(&g.counters[tid], 0);
-    if (tid < PAR_ITEM_SHARDS) g.item_counters[tid * PAR_ITEM_COUNTER_STRIDE] = 0;
+    if (tid < PAR_CNT_TOTAL && tid != PAR_CNT_ERROR) st_shared<COH>(&g.counters[tid], 0);  // (the error word is sticky)
+    if (tid < PAR_ITEM_LISTS * PAR_ITEM_SHARDS) g.item_counters[tid * PAR_ITEM_COUNTER_STRIDE] = 0;
 
     const int W = a.W, H = a.H, L = a.L, B = a.B;
     const int lane = threadIdx.x & 63;
@@ -655,14 +655,17 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     const int chunk_incl = wave_incl_scan_i(my_chunks, lane);
     const int pass_chunks = __shfl(chunk_incl, 63);
     const int first_item = chunk_incl - my_chunks;
-    const int tile_mode = (pass_chunks >= tile_chunks) ? 1 : 0;
+    // (a.tile_k == 0: a sparse frame, which has no launch for tile items: every column is visited entry by entry)
+    const int tile_mode = (a.tile_k > 0 && pass_chunks >= tile_chunks) ? 1 : 0;
     // a whole-tile visit is listed as items of tile_k consecutive chunks each (what a column's chunks share is then
-    // read once per item, render_tile_item), an entry-by-entry visit as one item per chunk
+    // read once per item, render_tile_item), in the list of the tile kernel; an entry-by-entry visit as one item per
+    // chunk in the list of the entry kernel
     const int tile_k = max(a.tile_k, 1);
-    const int tile_items = (tile_chunks + tile_k - 1) / tile_k;
+    const int tile_items = (int)(((uint32_t)(tile_chunks + tile_k - 1) * a.tile_k_magic) >> 16);
     const int n_items = (overflow || role != 0) ? 0 : (tile_mode ? tile_items : pass_chunks);
+    const int list_shard = tile_mode * PAR_ITEM_SHARDS + shard;
     int item_base = 0;
-    if (lane == 0 && n_items > 0) item_base = atomicAdd(&g.item_counters[shard * PAR_ITEM_COUNTER_STRIDE], n_items);
+    if (lane == 0 && n_items > 0) item_base = atomicAdd(&g.item_counters[list_shard * PAR_ITEM_COUNTER_STRIDE], n_items);
 
     // ---- B: the shadow walks of this wavefront's share of the occupied bins, one after the other ---------------
     constexpr int kWalkPart = PAR_COL_WALK / ROLES;
@@ -728,7 +731,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
         it.ci = usable ? (uint32_t)ci : PAR_ITEM_NONE;
         it.where = (uint32_t)bx | ((uint32_t)by << 10) | (simple ? PAR_ITEM_SIMPLE : 0u);
         it.bins = (uint32_t)bz_first | ((uint32_t)bz_last << 16);
-        par_item* dst = g.items + (size_t)shard * g.item_capacity + item_base;
+        par_item* dst = g.items + (size_t)list_shard * g.item_capacity + item_base;
         if (tile_mode) {
             it.entry = par_slot{0, 0, 0, 0, 0, 0, 0};
             for (int k = lane; k < n_items; k += 64) {
@@ -794,7 +797,12 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
             }
         }
     }
-    if (overflow && lane == 0) g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;  // the exception
+    if (overflow && lane == 0) {  // the exception
+        g.slow_list[atomicAdd(&g.counters[PAR_CNT_SLOW], 1)] = ci;
+        // (the host skips the overflow launch when its per-column pair counts rule an overflow out: should a column
+        // get here all the same, its pixels would silently keep the background -- say so)
+        if (!a.overflow_launched) atomicOr(&g.counters[PAR_CNT_ERROR], (int32_t)PAR_DEVERR_OVERFLOW);
+    }
     stamp(g, a.flags, 2, 4);
 }
 
@@ -973,20 +981,29 @@ __global__ __launch_bounds__(256) void resolve_fill_kernel(par_grid_dev g, par_b
 // L2, the fill's included: measured 14 us for this kernel). Every thread waits for its stores, one thread per
 // workgroup arrives on a counter and waits for the others; the last workgroup to leave resets the counters for the
 // next frame. The wait is bounded (a lost workgroup must not hang the GPU): should it
-// ever expire, the frame is wrong and g.counters[PAR_CNT_ERROR] says so.
-__device__ __forceinline__ void build_barrier(const par_grid_dev& g, int n_build) {
+// ever expire, resolve is skipped (the frame comes out empty) and the sticky g.counters[PAR_CNT_ERROR] says so; the
+// host reports it as PAR_ERR_DEVICE.
+// Returns false when the wait expired (some build workgroup never arrived): the caller then skips resolve, so that
+// the frame comes out visibly incomplete rather than subtly wrong, and the sticky error word says why.
+__device__ __forceinline__ bool build_barrier(const par_grid_dev& g, int n_build, bool test_skip_arrival,
+                                              int spin_bound) {
+    __shared__ int32_t timed_out;
     // every store of this thread has completed (the hand-over stores write through, st_shared)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) timed_out = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         int32_t* arrived = g.build_sync;
         int32_t* left = g.build_sync + 32;  // (a cache line apart)
-        __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (tests: this workgroup is "lost": it never arrives, the others wait until their bound and flag the frame;
+        // it leaves the counters as a frame without the fault would: the last to leave resets them)
+        if (!test_skip_arrival) __hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n_build) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1 << 22)) {  // ~ a second
-                g.counters[PAR_CNT_ERROR] = 1;
+            if (++spins > spin_bound) {
+                atomicOr(&g.counters[PAR_CNT_ERROR], (int32_t)PAR_DEVERR_BARRIER);
+                timed_out = 1;
                 break;
             }
         }
@@ -999,6 +1016,7 @@ __device__ __forceinline__ void build_barrier(const par_grid_dev& g, int n_build
     // acquire: drop what this XCD's L2 holds of the handed-over lines (two XCDs write neighbouring nodes of one
     // line; each keeps the line with its own part current and the other's stale). An invalidate, no write-back.
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return timed_out == 0;
 }
 
 template <int ENT>
@@ -1007,9 +1025,12 @@ __global__ __launch_bounds__(256) void build_fill_kernel(par_grid_dev g, par_bin
     stamp(g, a.flags, 0, 0);
     if ((int)blockIdx.x < n_build) {
         bin_insert_body<ENT, true>(g, b, (int)blockIdx.x, n_build);
-        build_barrier(g, n_build);
+        // (the bound: seconds in production -- a workgroup that is merely late must not be given up on --, tens of
+        // milliseconds in the test that loses one on purpose)
+        const bool met = build_barrier(g, n_build, b.test_lose_wg != 0 && blockIdx.x == 0,
+                                       b.test_lose_wg != 0 ? (1 << 14) : (1 << 22));
         stamp(g, a.flags, 0, 3);
-        bin_resolve_body<true>(g, b, (int)blockIdx.x, n_build);
+        if (met) bin_resolve_body<true>(g, b, (int)blockIdx.x, n_build);
     } else if (part.y != 0) {
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_build, (int)gridDim.x - n_build, part);
     }
@@ -1931,21 +1952,22 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
 // against 16 KB) -- workgroup v takes shard v mod shards, there the items (v / shards) * NW + its wavefront's
 // number, then on by n_waves / shards. The launch offers one wavefront per item of the host's bound (or per few),
 // so the loop runs once or a few times.
-template <bool DBG, bool IDS, bool FULL>
+template <bool DBG, bool IDS, bool FULL, bool TILES>
 __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
     const int lane = (int)threadIdx.x & 63;
     const int wg = w / PAR_WAVE_NW;
     const int shard = wg & (PAR_ITEM_SHARDS - 1);
-    const par_item* list = g.items + (size_t)shard * g.item_capacity;
+    const int list_shard = (TILES ? PAR_ITEM_SHARDS : 0) + shard;
+    const par_item* list = g.items + (size_t)list_shard * g.item_capacity;
     const int first = (wg >> PAR_ITEM_SHARD_BITS) * PAR_WAVE_NW + (w % PAR_WAVE_NW);
     // the first item is fetched beside the counter (the list is allocated whatever the counter says)
     u32x8 it = item_fetch(list + min(first, g.item_capacity - 1));
-    const int n = min(ld_uniform(g.item_counters + shard * PAR_ITEM_COUNTER_STRIDE), g.item_capacity);
+    const int n = min(ld_uniform(g.item_counters + list_shard * PAR_ITEM_COUNTER_STRIDE), g.item_capacity);
     item_arrived(it);
     stamp(g, DBG ? a.flags : 0u, 3, 1);
     for (int i = first; i < n;) {
         if (it[0] != PAR_ITEM_NONE) {
-            if ((it[1] >> 16) == PAR_ITEM_TILE) {
+            if (TILES) {
                 render_tile_item<DBG, IDS, FULL>(g, a, make_uint4(it[0], it[1], it[2], it[3]), lane);
             } else {
                 render_item<DBG, IDS, FULL>(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
@@ -1965,11 +1987,27 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid
     const unsigned long long core0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
     const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-    render_items<DBG, IDS, FULL>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
+    render_items<DBG, IDS, FULL, false>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
     stamp(g, DBG ? a.flags : 0u, 3, 7);
     if (DBG && g.stamps && (a.flags & (1u << 29)) && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
         // slot 5: the wavefront's life in shader-clock cycles (s_memtime), beside slots 0 / 7 in 100 MHz ticks
         g.stamps[((size_t)3 * PAR_STAMP_WGS + blockIdx.x) * PAR_STAMP_SLOTS + 5] = __builtin_amdgcn_s_memtime() - core0;
+    }
+}
+
+// The work items of the columns visited as whole tiles (render_tile_item): a kernel of its own, launched for DENSE
+// frames only (the host decides, par_render_args::tile_k). In one kernel with the entry passes either path would pay
+// for the other's registers -- the entry passes of a sparse frame are bound by latency and want every wavefront slot,
+// the tile pass is bound by instruction issue and wants its scalars in registers.
+template <bool DBG, bool IDS, bool FULL>
+__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_tiles_kernel(par_grid_dev g, par_render_args a) {
+    stamp(g, DBG ? a.flags : 0u, 5, 0);
+    const unsigned long long core0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
+    const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
+    render_items<DBG, IDS, FULL, true>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
+    stamp(g, DBG ? a.flags : 0u, 5, 7);
+    if (DBG && g.stamps && (a.flags & (1u << 29)) && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
+        g.stamps[((size_t)5 * PAR_STAMP_WGS + blockIdx.x) * PAR_STAMP_SLOTS + 5] = __builtin_amdgcn_s_memtime() - core0;
     }
 }
 
@@ -1994,21 +2032,27 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_overflow_kernel(par_g
     stamp(g, a.flags, 4, 7);
 }
 
-// Both of the above in one launch, for small frames: there a frame is bound by its launches (the host enqueues one
-// in about 3 us, the device needs about 1.5 us between two), not by the registers the overflow path costs the others.
-// Workgroups [0, n_item_wgs) render the work items, the rest (groups of `over_parts`) the overflow list.
+// All of the above in one launch, for small frames: there a frame is bound by its launches (the host enqueues one in
+// about 3 us, the device needs about 1.5 us between two), not by the registers the paths cost each other.
+// Workgroups [0, n_item_wgs) render the entry items, [n_item_wgs, n_item_wgs + n_tile_wgs) the tile items, the rest
+// (groups of `over_parts`) the overflow list.
 template <bool DBG>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_dev g, par_render_args a,
-                                                                          int n_item_wgs, int over_parts) {
+                                                                          int n_item_wgs, int n_tile_wgs, int over_parts) {
     __shared__ WaveScratch scratch[PAR_WAVE_NW];
     const int b = (int)blockIdx.x;
     if (b < n_item_wgs) {
         const int w = __builtin_amdgcn_readfirstlane(b * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-        render_items<DBG, true, true>(g, a, w, n_item_wgs * PAR_WAVE_NW);
+        render_items<DBG, true, true, false>(g, a, w, n_item_wgs * PAR_WAVE_NW);
         return;
     }
-    const int j = b - n_item_wgs;  // (workgroups of this kind exist only when some column may overflow)
-    const int stride = ((int)gridDim.x - n_item_wgs) / over_parts;
+    if (b < n_item_wgs + n_tile_wgs) {
+        const int w = __builtin_amdgcn_readfirstlane((b - n_item_wgs) * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
+        render_items<DBG, true, true, true>(g, a, w, n_tile_wgs * PAR_WAVE_NW);
+        return;
+    }
+    const int j = b - n_item_wgs - n_tile_wgs;  // (workgroups of this kind exist only when some column may overflow)
+    const int stride = ((int)gridDim.x - n_item_wgs - n_tile_wgs) / over_parts;
     const int n_slow = g.counters[PAR_CNT_SLOW];
     for (int s = j / over_parts; s < n_slow; s += stride) {
         render_column_generic(g, a, g.slow_list[s], j % over_parts, over_parts, scratch);
@@ -2311,8 +2355,31 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     return hipGetLastError();
 }
 
-// Small frames: work items and overflowed columns in one launch. hipErrorNotSupported (nothing launched) for large
-// frames, where the two kernels' different register needs matter.
+// Tile items cover a.tile_k chunks each: `item_bound` chunks are at most that many fewer items (rounded up per column,
+// which the bound's slack of one item per column covers).
+static int64_t tile_item_bound(const par_render_args& a, int64_t item_bound) {
+    const int64_t k = a.tile_k > 0 ? a.tile_k : 1;
+    return (item_bound + k - 1) / k + 1;
+}
+
+hipError_t par_launch_render_tiles(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
+                                   hipStream_t stream) {
+    if (item_bound <= 0 || a.dense || a.tile_k <= 0) return hipSuccess;
+    // (several items per wavefront in big frames, item_workgroups: full floor at 4096^2, tile_k 5: 220 us with one
+    // item per wavefront, 197 with three)
+    const dim3 grid((unsigned)item_workgroups(tile_item_bound(a, item_bound))), block(PAR_WAVE_NW * 64);
+    if (a.flags & PAR_DEBUG_FLAGS) {
+        hipLaunchKernelGGL((render_tiles_kernel<true, true, true>), grid, block, 0, stream, g, a);
+    } else if (a.sprite_ids || a.out.brightness || a.out.lit || a.out.gbuf) {
+        hipLaunchKernelGGL((render_tiles_kernel<false, true, true>), grid, block, 0, stream, g, a);
+    } else {
+        hipLaunchKernelGGL((render_tiles_kernel<false, false, false>), grid, block, 0, stream, g, a);
+    }
+    return hipGetLastError();
+}
+
+// Small frames: work items, tile items and overflowed columns in one launch. hipErrorNotSupported (nothing launched)
+// for large frames, where the kernels' different register needs matter.
 hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                   int64_t item_bound, bool may_overflow, hipStream_t stream) {
     const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
@@ -2322,12 +2389,14 @@ hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& 
     const int over_parts = 8;
     const int64_t over_cols = !may_overflow ? 0 : (bound < 32 ? bound : 32);
     const int64_t n_item_wgs = item_workgroups(item_bound);
+    const int64_t n_tile_wgs = a.tile_k > 0 ? item_workgroups(tile_item_bound(a, item_bound)) : 0;
+    const dim3 grid((unsigned)(n_item_wgs + n_tile_wgs + over_cols * over_parts));
     if (a.flags & PAR_DEBUG_FLAGS) {
-        hipLaunchKernelGGL(render_both_kernel<true>, dim3((unsigned)(n_item_wgs + over_cols * over_parts)),
-                           dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs, over_parts);
+        hipLaunchKernelGGL(render_both_kernel<true>, grid, dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs,
+                           (int)n_tile_wgs, over_parts);
     } else {
-        hipLaunchKernelGGL(render_both_kernel<false>, dim3((unsigned)(n_item_wgs + over_cols * over_parts)),
-                           dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs, over_parts);
+        hipLaunchKernelGGL(render_both_kernel<false>, grid, dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs,
+                           (int)n_tile_wgs, over_parts);
     }
     return hipGetLastError();
 }

@@ -21,6 +21,7 @@ const char* par_status_string(int status) {
         case PAR_ERR_EXTENT: return "AABB extent not expressible by the 20x40 sprite";
         case PAR_ERR_SPRITE_ID: return "sprite id or palette index out of range";
         case PAR_ERR_NOT_READY: return "scene incomplete (sprites, entities and light must be set)";
+        case PAR_ERR_DEVICE: return "a kernel reported a failure: a frame rendered since the last check is not valid";
         default: return "unknown status";
     }
 }

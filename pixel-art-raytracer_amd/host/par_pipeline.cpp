@@ -246,8 +246,8 @@ int main(int argc, char** argv) {
 
     if (stamps_from >= 0) {
         // rows: the frame's kernels; per workgroup 8 slots, slot 0 = start, slot 7 = end (100 MHz ticks)
-        static const char* names[5] = {"insert+fill", "resolve+fill", "columns+fill", "render_items", "render_overflow"};
-        const size_t rows = 5, wgs = 8192, n = rows * wgs * 8;
+        static const char* names[6] = {"insert+fill", "resolve+fill", "columns+fill", "render_items", "render_overflow", "render_tiles"};
+        const size_t rows = 6, wgs = 8192, n = rows * wgs * 8;
         std::vector<std::vector<unsigned long long>> st(slots.size(), std::vector<unsigned long long>(n));
         unsigned long long t_min = ~0ull;
         for (size_t k = 0; k < slots.size(); k++) {
@@ -274,7 +274,7 @@ int main(int argc, char** argv) {
                     if (e > b) life += e - b;
                 }
                 if (!cnt) continue;
-                static const int waves[5] = {4, 4, 2, 2, 2};  // wavefronts per workgroup of each kernel
+                static const int waves[6] = {4, 4, 2, 4, 4, 4};  // wavefronts per workgroup of each kernel
                 std::printf("stamps frame %d slot %zu %-16s start %8.2f  last-wg-start %8.2f  end %8.2f  (%.2f us, %zu wgs, "
                             "%.0f wavefront-us)\n",
                             f, k, names[r], (a0 - t_min) * 0.01, (last_start - t_min) * 0.01, (a1 - t_min) * 0.01,

@@ -104,8 +104,8 @@ class FramePipeline:
     def kernel_spans_us(self):
         """Per kernel of the frame, the mean span (first workgroup start to last workgroup end, microseconds) over the
         slots' most recent frames rendered with flag bit 29 (needs PAR_DEBUG_STAMPS=1 when the contexts were made)."""
-        names = ("build_fill", "resolve_fill", "columns_fill", "render_items", "render_overflow")
-        rows, wgs = 5, 8192
+        names = ("build_fill", "resolve_fill", "columns_fill", "render_items", "render_overflow", "render_tiles")
+        rows, wgs = 6, 8192
         spans = {k: [] for k in names}
         buf = np.zeros(rows * wgs * 8, dtype=np.uint64)
         for s in self.slots:

@@ -794,3 +794,68 @@ def test_one_launch_hash_build_equals_two_launches(par, oracle, sprite, T):
                 exp = oracle.render(params, aabbs, sprite, light, planes=("fb", "palidx"), nthreads=8)
                 assert np.array_equal(bufs[0]["fb"].cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
                 assert np.array_equal(bufs[0]["palidx"].cpu().numpy(), exp["palidx"]), f"frame {f}"
+
+
+def test_device_failure_is_reported_through_the_abi():
+    """A kernel-side failure surfaces as PAR_ERR_DEVICE, once, from the first call that waits for the device.
+    PAR_TEST_LOSE_BUILD_WG=1 (read once per process: fresh process) makes build workgroup 0 of the one-launch hash build
+    never arrive at its barrier; the others give up after their (shortened) bound, skip resolve and set the sticky
+    error word. The frame is then empty, and every entry point that synchronises says so."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import importlib, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+par = importlib.import_module("pixel-art-raytracer_amd"); T = par.types
+params = T.default_params(512, 512, 512)
+aabbs, light = par.scene_synthetic(64, 512, 512, 512, 12345)
+with par.Renderer(params) as r:
+    r.set_scene(aabbs, par.tile_floor(), light)
+    try:
+        r.render(("fb",))
+        raise SystemExit("par_render did not report the lost workgroup")
+    except par.ParError as e:
+        assert e.status == 9, e.status       # PAR_ERR_DEVICE
+    # the asynchronous entry point cannot see it; the next call that waits does, once
+    fb = torch.zeros(512 * 512 * 4, dtype=torch.uint8, device="cuda")
+    r.render_device({"fb": fb.data_ptr()}, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    try:
+        r.stats()
+        raise SystemExit("par_get_stats did not report the lost workgroup")
+    except par.ParError as e:
+        assert e.status == 9, e.status
+    st = r.stats()                            # reported once: the flag is clear again, no frame since
+    assert st.occupied_columns == 0           # (resolve was skipped: the failed frame is visibly empty)
+    assert not fb.cpu().numpy().reshape(-1, 4)[:, 3].any() and (fb.cpu().numpy().reshape(-1, 4)[:, 0] == 31).all()
+print("device error ok")
+''' % root
+    env = dict(os.environ, PAR_TEST_LOSE_BUILD_WG="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "device error ok" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])
+
+
+@pytest.mark.parametrize("pairs", [30, 31, 32, 33, 34])
+def test_columns_at_the_edge_of_a_record(par, oracle, sprite, T, pairs):
+    """One screen column with `pairs` (entity, bin) pairs, around what the host takes as the sure capacity of a column
+    record (32): up to there the frame is enqueued WITHOUT a launch for the overflow list, beyond it with one. Either
+    way the picture is the oracle's, no column is left on an overflow list nobody renders (the device would flag
+    that: PAR_ERR_DEVICE from stats()), and overflow_columns is 0 whenever the launch was skipped."""
+    w, h, l = 480, 320, 1400
+    params = T.default_params(w, h, l)
+    # boxes with y + z constant stay on the same screen rows: one box per z-bin of screen column (2, 5)
+    rows = [(90 + (b % 7), 190 - 40 * b, 40 * b + 10, 20, 20, 20) for b in range(pairs)]
+    rows += [(i * 20, 0, j * 20, 20, 20, 20) for i in range(10, 24) for j in range(0, 16)]
+    aabbs = T.make_aabbs(rows)
+    light = T.make_light(300, 160, 80)
+    exp = oracle.render(params, aabbs, sprite, light)
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        planes = ("fb", "palidx", "brightness", "gbuf")
+        assert_planes_equal(r.render(planes), exp, planes, f"{pairs} pairs")
+        st = r.stats()  # (raises PAR_ERR_DEVICE if a column overflowed with no launch for the list)
+        if pairs <= 32:
+            assert st.overflow_columns == 0

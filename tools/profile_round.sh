@@ -17,4 +17,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o pmc -- python3 tools/frames.py synthetic 40 > $out/pmc_$c.log 2> $out/rocprof_pmc_$c.err
 done
 python3 tools/hbm_traffic.py $out "$commit" > $out/hbm_traffic.json
+for w in synthetic floor graybox; do
+  rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $out/sq_$w -o pmc -- python3 tools/frames.py $w 30 > $out/sq_$w.log 2> $out/rocprof_sq_$w.err
+done
+python3 tools/sq_counters.py $out "$commit" > $out/sq_counters.json
 find $out -name "*stats*.csv" | head

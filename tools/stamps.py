@@ -21,13 +21,13 @@ for _ in range(20):
     r.render_device(ptrs, stream=s)
 r.render_device(ptrs, stream=s, flags=1 << 29)  # the stamped frame
 torch.cuda.synchronize()
-n = 5 * 8192 * 8
+n = 6 * 8192 * 8
 buf = np.zeros(n, dtype=np.uint64)
 L_ = par.lib()
 L_.par_debug_read_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 rc = L_.par_debug_read_stamps(r._ctx, buf.ctypes.data_as(C.c_void_p), n)
 assert rc == 0, rc
-st = buf.reshape(5, 8192, 8).astype(np.float64) * 0.01  # us (100 MHz)
+st = buf.reshape(6, 8192, 8).astype(np.float64) * 0.01  # us (100 MHz)
 ncol = int(r.stats().occupied_columns)
 for row, name in enumerate(["insert+fill", "resolve+fill", "columns+fill", "render_items", "render_overflow"]):
     x = st[row]
@@ -54,7 +54,7 @@ if ok3.any():
     for i in range(1, 6):
         d = x3[ok3, idx3[i]] - x3[ok3, idx3[i - 1]]
         print(f"   {names3[i-1]:>20s} -> {names3[i]:<20s}: median {np.median(d):5.2f}  p90 {np.percentile(d,90):5.2f}  max {d.max():5.2f} us")
-    cyc = buf.reshape(5, 8192, 8)[3][ok3, 5].astype(np.float64)
+    cyc = buf.reshape(6, 8192, 8)[3][ok3, 5].astype(np.float64)
     life = x3[ok3, 7] - x3[ok3, 0]
     print(f"   shader clock while a render wavefront lives: median {np.median(cyc / life):.0f} MHz "
           f"({np.median(cyc):.0f} cycles in {np.median(life):.2f} us)")
