@@ -8,8 +8,10 @@
 A step = one frame of the hot path (alt:690-760 of the reference): rebuild the spatial hash from the resident
 AABBs, cast one primary and one shadow ray per pixel, shade, quantise — writing the RGBA8 frame and the
 palette-index plane. Scene, sprites and output buffers are resident in HBM before the timed region. With N > 1 the
-same frame is sharded by row block (cut at bin rows, pixel-art-raytracer_amd/sharding.py) and the blocks are gathered
-to rank 0 with one RCCL gather per frame (strong scaling: total work is fixed as N grows).
+same frame is sharded by row block (cut at bin rows, pixel-art-raytracer_amd/sharding.py) and assembled on rank 0
+(strong scaling: total work is fixed as N grows): by default only the tiles that can show a primitive travel (RCCL
+point to point) and rank 0 writes the background itself (`--assemble tiles`); `--assemble blocks` gathers whole row
+blocks with one RCCL gather per frame; `--assemble none` leaves the frame sharded (render scaling on its own).
 
 Frames in flight: like a swap chain, `--inflight` (default 4) frames are in flight at once, each with its own context,
 stream and output buffers (pixel-art-raytracer_amd/pipeline.py); one frame alone is a chain of short latency-bound
@@ -253,6 +255,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the dense / default-scene side measurements")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for tests)")
     ap.add_argument("--share-gpu", action="store_true", help="tests: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--assemble", choices=("tiles", "blocks", "none"), default="tiles",
+                    help="N > 1: how the frame is assembled on rank 0: only the tiles that can show a primitive travel "
+                         "and rank 0 writes the background (default), whole row blocks (one RCCL gather), or not at all "
+                         "(the frame stays sharded: render scaling on its own)")
     ap.add_argument("--size", type=int, default=W, help="view size (the headline benchmark is 4096; BASELINE config 3: 2048)")
     ap.add_argument("--prims", type=int, default=N_PRIMS, help="primitives (headline 1024; BASELINE config 3: 256)")
     args = ap.parse_args()
@@ -296,27 +302,46 @@ def main():
 
     r0, r1 = sharding.row_block(rank, world, H, params.bin_size)
     has_rows = r1 > r0
-    gather = None
+    gather = None      # "blocks": one FrameGather
+    tile_gathers = []  # "tiles": one TileGather per frame slot (each frame in flight has its own inbox and frame)
     rows_alloc = H
-    if world > 1:
-        gather = sharding.FrameGather(H, W * 4, torch.uint8, dev, world, rank, bin_size=params.bin_size)
-        rows_alloc = max(gather.max_rows, 1)
     depth = max(1, args.inflight)
+    if world > 1:
+        rows_alloc = max(sharding.max_block_rows(world, H, params.bin_size), 1)
+        if args.assemble == "blocks":
+            gather = sharding.FrameGather(H, W * 4, torch.uint8, dev, world, rank, bin_size=params.bin_size)
+        elif args.assemble == "tiles":
+            tile_gathers = [sharding.TileGather(params, aabbs, dev, world, rank) for _ in range(depth)]
     pipe = pipeline.FramePipeline(params, aabbs, sprite, light, depth=depth, device=local_rank,
                                   rows=(r0, r1) if has_rows else (0, 1), planes=("fb", "palidx"), rows_alloc=rows_alloc)
     r = pipe.slots[0].renderer
     fb = [s_.buffers["fb"] for s_ in pipe.slots]
     pal = [s_.buffers["palidx"] for s_ in pipe.slots]
 
-    def step(i, flags=0):  # N > 1: render + gather per frame (the interpreter is not what bounds that path)
+    packed = [tg.packed_buffer() for tg in tile_gathers]
+
+    def exchange(slot, k):
+        """Behind the render of slot k's block, on the slot's stream: the frame's exchange step."""
+        if tile_gathers:
+            tg = tile_gathers[k]
+            if has_rows:
+                tg.pack(slot.buffers["fb"], packed[k], stream=slot.stream.cuda_stream)
+            work = tg.exchange(packed[k], async_op=True)
+            if rank == 0:
+                work.wait()  # (RCCL: the slot's stream waits, not the host)
+                tg.assemble(stream=slot.stream.cuda_stream)
+            return work
+        return gather.gather(slot.buffers["fb"], async_op=True)
+
+    def step(i, flags=0):  # N > 1: render + exchange per frame (the interpreter is not what bounds that path)
         slot = pipe.slot(i)
-        with torch.cuda.stream(slot.stream):  # the collective is ordered after the render on the slot's stream
-            if slot.pending is not None:      # the gather that last read this slot's block buffer
+        with torch.cuda.stream(slot.stream):  # the exchange is ordered after the render on the slot's stream
+            if slot.pending is not None:      # the exchange that last read this slot's buffers
                 slot.pending.wait()
                 slot.pending = None
             if has_rows:
                 pipe.submit(i, flags)
-            slot.pending = gather.gather(slot.buffers["fb"], async_op=True)
+            slot.pending = exchange(slot, i % depth)
 
     def drain():
         for slot in pipe.slots:
@@ -331,7 +356,8 @@ def main():
 
     def run_block(first, n, flags=0):
         """Exactly n steps, drained."""
-        if gather is None:
+        if gather is None and not tile_gathers:
+            # (N = 1, or a frame that stays sharded: nothing but the render)
             pipe.submit_many(first, n, flags)  # the swap chain's loop runs in the library, one call
             torch.cuda.synchronize()           # (one device-wide wait: every slot's stream is done)
         else:
@@ -358,10 +384,21 @@ def main():
     verified_gpu = None
     hit_pixels = 0
     full = None
+    if world > 1 and args.assemble == "none":
+        # the frame stays sharded: every rank holds its block against its own render of the whole frame
+        mine = r.render(("fb",))["fb"].view(np.uint8)
+        ok = all(bool(np.array_equal(fb[k].cpu().numpy()[:(r1 - r0) * W * 4], mine[r0 * W * 4:r1 * W * 4]))
+                 for k in range(depth)) if has_rows else True
+        verified_gpu = bool(reduce_max(0.0 if ok else 1.0) == 0.0)
     if rank == 0:
         full = r.render(("fb", "palidx"))
-        if world > 1:
+        if world > 1 and tile_gathers:
+            verified_gpu = all(bool(np.array_equal(tg.frame.cpu().numpy(), full["fb"].view(np.uint8)))
+                               for tg in tile_gathers)
+        elif world > 1 and gather is not None:
             verified_gpu = bool(np.array_equal(gather.frame.cpu().numpy(), full["fb"].view(np.uint8)))
+        elif world > 1:
+            pass  # (verified above, on every rank)
         else:
             verified_gpu = all(bool(np.array_equal(fb[k].cpu().numpy(), full["fb"].view(np.uint8)) and
                                     np.array_equal(pal[k].cpu().numpy(), full["palidx"])) for k in range(depth))
@@ -415,7 +452,11 @@ def main():
             "config": {"workload": f"{W}x{H}x{L} view, bin 40, {N_PRIMS} primitives (splitmix64 seed {SEED}), "
                                    f"light ({5 * W // 8},{H // 2},{L // 4}); RGBA8 frame + palette-index plane",
                        "sharding": f"row blocks over {world} GPU(s), cut at bin rows" +
-                                   (", RCCL gather to rank 0" if world > 1 else ""),
+                                   ("" if world == 1 else
+                                    {"tiles": ", the tiles that can show a primitive sent to rank 0 over RCCL (point to "
+                                              "point), rank 0 writes the background",
+                                     "blocks": ", one RCCL gather of the row blocks to rank 0",
+                                     "none": ", the frame left sharded (no exchange)"}[args.assemble]),
                        "frames_in_flight": depth, "streams_overlap_pairwise": bool(pipe.streams_overlap),
                        "note": "value is a rate with frames_in_flight frames in flight; one_frame_at_a_time is the "
                                "latency of a frame on its own"},
@@ -446,13 +487,15 @@ def main():
             slot.stream.synchronize()
         render_ms = (time.perf_counter() - t0) / reps * 1e3
         barrier()
-        t0 = time.perf_counter()
-        for i in range(reps):
-            with torch.cuda.stream(slot.stream):
-                w_ = gather.gather(slot.buffers["fb"], async_op=True)
-                w_.wait()
-            slot.stream.synchronize()
-        gather_ms = (time.perf_counter() - t0) / reps * 1e3
+        gather_ms = 0.0
+        if args.assemble != "none":
+            t0 = time.perf_counter()
+            for i in range(reps):
+                with torch.cuda.stream(slot.stream):
+                    w_ = exchange(slot, 0)
+                    w_.wait()
+                slot.stream.synchronize()
+            gather_ms = (time.perf_counter() - t0) / reps * 1e3
         names = [None] * world
         dist.all_gather_object(names, f"rank {rank}: {torch.cuda.get_device_name(local_rank)} (cuda:{local_rank}), "
                                       f"rows {r0}..{r1}")
@@ -461,11 +504,19 @@ def main():
         worst_render = reduce_max(render_ms)
         if rank == 0:
             out["multi_gpu"] = {
+                "assemble": args.assemble,
                 "render_ms": round(worst_render, 5), "gather_ms": round(gather_ms, 5),
-                "gather_bytes_per_rank": int(gather.max_rows * W * 4), "ranks_seen": names,
+                "gather_bytes_per_rank": (int(rows_alloc * W * 4) if args.assemble == "blocks" else
+                                          (max(tile_gathers[0].bytes_sent(q) for q in range(world)) if tile_gathers else 0)),
+                "tiles": ({"total": int(len(tile_gathers[0].tiles)), "of": int(np.prod(params.grid_dims()[:2])),
+                           "per_rank": [int(c) for c in tile_gathers[0].counts],
+                           "bytes_to_rank0": int(sum(tile_gathers[0].bytes_sent(q) for q in range(world)))}
+                          if tile_gathers else None),
+                "ranks_seen": names,
                 "ramp_iterations": ramp_counts,  # (untimed clock ramp: the same on every rank by construction)
                 "note": "render_ms: one frame's row block rendered and waited for, one at a time (maximum over ranks); "
-                        "gather_ms: one gather of the blocks to rank 0 on its own, waited for; the timed region "
+                        "gather_ms: one frame's exchange step on its own (pack, send to rank 0, background and unpack "
+                        "there; or the gather of the blocks), waited for; the timed region "
                         "overlaps both over the frames in flight",
             }
 

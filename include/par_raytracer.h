@@ -191,6 +191,28 @@ int par_scene_synthetic(int n, int width, int height, int length, uint64_t seed,
  * covering [0, height), cut at multiples of the bin size (a bin row of 40 screen rows never straddles two ranks), the
  * bin rows dealt as evenly as they go. */
 void par_row_block(int rank, int ranks, int height, int bin_size, int* begin, int* end);
+/* --- sharded frames: assembling only what can differ from the background ----------------------------
+ * A frame sharded by row blocks over the GPUs of a node is assembled on one of them. Most of a sparse frame is the
+ * constant background, which the assembling rank can write itself: only the screen TILES (bin footprints, bin_size x
+ * bin_size pixels) that can show a primitive need to travel. Every rank holds the whole scene, so every rank derives
+ * the same tile list (no exchange of metadata), sorted by bin row: a rank's row block is a contiguous run of it. */
+
+/* The tiles that can show a primitive: the screen columns the entities reach by the cull and bin ranges of
+ * alt:212-240 (a superset of the columns the spatial hash will mark occupied). Host arithmetic, no GPU needed.
+ * tiles[i] = bx | by << 16, sorted by (by, bx). Returns the number of such tiles (writes at most `capacity`), or a
+ * negative par_status. */
+int par_scene_tiles(const par_params* params, const par_aabb* aabbs, int n, int32_t* tiles, int capacity);
+/* Copy tiles d_tiles[0, n) (device array) out of a frame block -- rows [row_begin, row_end) of the frame, stored
+ * at `fb_block` -- into `packed`: n slots of bin_size x bin_size pixels, slot i row-major. Pixels of a slot beyond the
+ * view's right / bottom edge are not written. Asynchronous on `stream` (a hipStream_t); device pointers. */
+int par_tiles_pack(const par_params* params, void* stream, const int32_t* d_tiles, int n, const par_color* fb_block,
+                   int row_begin, int row_end, par_color* packed);
+/* The inverse on the assembling rank: slots -> their place in the whole frame (`frame` addresses row 0). */
+int par_tiles_unpack(const par_params* params, void* stream, const int32_t* d_tiles, int n, const par_color* packed,
+                     par_color* frame);
+/* The background (Color{background} * ambient, alt:281, 735) for n_rows whole rows starting at `rows`. */
+int par_background_fill(const par_params* params, void* stream, par_color* rows, int n_rows);
+
 /* Debug overlay of alt:763-772 (Bresenham line from the picked pixel to the light) drawn into a host frame. */
 void par_debug_line(const par_params* params, const par_pixel* pick, int mouse_x, const par_light* light,
                     par_color* fb);

@@ -38,7 +38,8 @@ ABI_SYMBOLS = (
     "par_set_light", "par_render", "par_render_rows", "par_render_device", "par_render_device_timed",
     "par_graph_capture", "par_graph_stage", "par_graph_launch", "par_pick", "par_get_stats", "par_read_grid",
     "par_sprite_tile_floor", "par_scene_graybox", "par_scene_synthetic", "par_debug_line", "par_debug_units",
-    "par_render_device_slots", "par_row_block",
+    "par_render_device_slots", "par_row_block", "par_scene_tiles", "par_tiles_pack", "par_tiles_unpack",
+    "par_background_fill",
 )
 
 
@@ -115,6 +116,10 @@ def lib():
         L.par_render_device_slots.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, C.c_uint]
         L.par_row_block.restype = None
         L.par_row_block.argtypes = [i32, i32, i32, i32, vp, vp]
+        L.par_scene_tiles.argtypes = [vp, vp, i32, vp, i32]
+        L.par_tiles_pack.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
+        L.par_tiles_unpack.argtypes = [vp, vp, vp, i32, vp, vp]
+        L.par_background_fill.argtypes = [vp, vp, vp, i32]
         L.par_debug_read_stamps.argtypes = [vp, vp, C.c_size_t]
         L.par_debug_line.restype = None
         L.par_debug_line.argtypes = [vp, vp, i32, vp, vp]
@@ -321,3 +326,36 @@ class Renderer:
 
 def plane_bytes(plane):
     return _PLANE_BYTES[plane]
+
+
+def scene_tiles(params, aabbs):
+    """The screen tiles (bx | by << 16, sorted by bin row then bin column) that can show a primitive of the scene
+    (par_scene_tiles: host arithmetic, the same list on every rank of a sharded frame)."""
+    a = np.ascontiguousarray(aabbs, dtype=AABB)
+    gx, gy, _ = params.grid_dims()
+    tiles = np.zeros(gx * gy, dtype=np.int32)
+    n = lib().par_scene_tiles(C.byref(params), ptr(a), len(a), ptr(tiles), len(tiles))
+    if n < 0:
+        raise ParError(-n, "par_scene_tiles")
+    return tiles[:n].copy()
+
+
+def tiles_pack(params, d_tiles, n, fb_block, rows, packed, stream=0):
+    """Device pointers (ints): tiles d_tiles[0, n) of the frame block `rows` at fb_block -> packed slots (asynchronous)."""
+    rc = lib().par_tiles_pack(C.byref(params), C.c_void_p(stream), C.c_void_p(d_tiles), n, C.c_void_p(fb_block), rows[0],
+                              rows[1], C.c_void_p(packed))
+    if rc != PAR_OK:
+        raise ParError(rc, "par_tiles_pack")
+
+
+def tiles_unpack(params, d_tiles, n, packed, frame, stream=0):
+    rc = lib().par_tiles_unpack(C.byref(params), C.c_void_p(stream), C.c_void_p(d_tiles), n, C.c_void_p(packed),
+                                C.c_void_p(frame))
+    if rc != PAR_OK:
+        raise ParError(rc, "par_tiles_unpack")
+
+
+def background_fill(params, rows_ptr, n_rows, stream=0):
+    rc = lib().par_background_fill(C.byref(params), C.c_void_p(stream), C.c_void_p(rows_ptr), n_rows)
+    if rc != PAR_OK:
+        raise ParError(rc, "par_background_fill")

@@ -1219,6 +1219,37 @@ int par_render_device_slots(par_context* const* ctxs, void* const* streams, cons
     });
 }
 
+// ---- sharded frames: tiles and background (context-free: the parameters say all that is needed) -------------
+static int tiles_args_ok(const par_params* p, int n) {
+    return p && n >= 0 && p->width > 0 && p->height > 0 && p->bin_size >= PAR_MIN_BIN && p->bin_size <= PAR_MAX_BIN;
+}
+int par_tiles_pack(const par_params* p, void* stream, const int32_t* d_tiles, int n, const par_color* fb_block,
+                   int row_begin, int row_end, par_color* packed) {
+    if (!tiles_args_ok(p, n) || (n > 0 && (!d_tiles || !fb_block || !packed)) || row_begin < 0 || row_end > p->height ||
+        row_begin > row_end) {
+        return PAR_ERR_INVALID_ARG;
+    }
+    const hipError_t e = par_launch_tiles_copy(true, d_tiles, n, p->width, p->height, p->bin_size, row_begin, row_end,
+                                               fb_block, packed, (hipStream_t)stream);
+    return e == hipSuccess ? PAR_OK : PAR_ERR_HIP;
+}
+int par_tiles_unpack(const par_params* p, void* stream, const int32_t* d_tiles, int n, const par_color* packed,
+                     par_color* frame) {
+    if (!tiles_args_ok(p, n) || (n > 0 && (!d_tiles || !frame || !packed))) return PAR_ERR_INVALID_ARG;
+    const hipError_t e = par_launch_tiles_copy(false, d_tiles, n, p->width, p->height, p->bin_size, 0, p->height, packed,
+                                               frame, (hipStream_t)stream);
+    return e == hipSuccess ? PAR_OK : PAR_ERR_HIP;
+}
+int par_background_fill(const par_params* p, void* stream, par_color* rows, int n_rows) {
+    if (!p || n_rows < 0 || (n_rows > 0 && !rows) || p->width <= 0 || !(p->ambient >= 0.f && p->ambient <= 1.f)) {
+        return PAR_ERR_INVALID_ARG;
+    }
+    const uint32_t ch = (uint32_t)(uint8_t)((float)p->background * p->ambient);  // Color{127,127,127,0} * ambient
+    const hipError_t e = par_launch_background(rows, (size_t)n_rows * (size_t)p->width, ch | (ch << 8) | (ch << 16),
+                                               (hipStream_t)stream);
+    return e == hipSuccess ? PAR_OK : PAR_ERR_HIP;
+}
+
 // ---- the exported entry points of the bodies above: no exception leaves the library -----------------------
 int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) {
     return guarded(ctx, [&] { return par_set_sprites_impl(ctx, sprites, n_sprites); });

@@ -1981,8 +1981,13 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     }
 }
 
+#if defined(PAR_RENDER_SGPRS)  // (experiments: cap the entry kernel's scalar registers, tools/debug/variants.sh)
+#define PAR_RENDER_ATTR __attribute__((amdgpu_num_sgpr(PAR_RENDER_SGPRS)))
+#else
+#define PAR_RENDER_ATTR
+#endif
 template <bool DBG, bool IDS, bool FULL>
-__global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_items_kernel(par_grid_dev g, par_render_args a) {
+__global__ __launch_bounds__(PAR_WAVE_NW * 64) PAR_RENDER_ATTR void render_items_kernel(par_grid_dev g, par_render_args a) {
     stamp(g, DBG ? a.flags : 0u, 3, 0);
     const unsigned long long core0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
@@ -2409,6 +2414,68 @@ hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_ar
     // overflowed columns are the exception: a small strided grid (up to 8 workgroups share a column)
     const int64_t oblocks = a.dense ? (bound < 1024 ? bound : 1024) : (bound < 32 ? bound : 32);
     hipLaunchKernelGGL(render_overflow_kernel, dim3((unsigned)oblocks, 8u), dim3(PAR_WAVE_NW * 64), 0, stream, g, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Sharded frames: the tiles that travel. One workgroup per tile; a tile's row is bin_size consecutive
+// pixels in the frame and in the slot (coalesced both ways); pixels beyond the view's edge are left alone.
+// PACK: frame block -> slots, else slots -> frame.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+template <bool PACK>
+__global__ __launch_bounds__(256) void tiles_copy_kernel(const int32_t* tiles, int n, int W, int H, int B, int row_begin,
+                                                          int row_end, const uint32_t* src, uint32_t* dst) {
+    const int t = (int)blockIdx.x;
+    if (t >= n) return;
+    const int tile = tiles[t];
+    const int c0 = (tile & 0xFFFF) * B, r0 = (tile >> 16) * B;
+    const int tw = min(B, W - c0);
+    const int rows_lo = max(r0, row_begin), rows_hi = min(min(r0 + B, H), row_end);
+    const uint32_t* s = src;
+    uint32_t* d = dst;
+    for (int p = (int)threadIdx.x; p < B * B; p += (int)blockDim.x) {
+        const int y = p / B, x = p - y * B;
+        const int row = r0 + y;
+        if (x >= tw || row < rows_lo || row >= rows_hi) continue;
+        const size_t in_frame = (size_t)(row - row_begin) * (size_t)W + (size_t)(c0 + x);
+        const size_t in_slot = (size_t)t * (size_t)(B * B) + (size_t)p;
+        if (PACK) d[in_slot] = s[in_frame];
+        else d[in_frame] = s[in_slot];
+    }
+}
+
+__global__ __launch_bounds__(256) void background_rows_kernel(uint32_t* dst, size_t n_px, uint32_t rgba) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const size_t n4 = n_px >> 2;
+    const u32x4 v = {rgba, rgba, rgba, rgba};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst) + i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n_px & 3)) dst[(n4 << 2) + threadIdx.x] = rgba;
+}
+}  // namespace
+
+hipError_t par_launch_tiles_copy(bool pack, const int32_t* d_tiles, int n, int W, int H, int B, int row_begin, int row_end,
+                                 const void* src, void* dst, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    if (pack) {
+        hipLaunchKernelGGL(tiles_copy_kernel<true>, dim3((unsigned)n), dim3(256), 0, stream, d_tiles, n, W, H, B, row_begin,
+                           row_end, static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst));
+    } else {
+        hipLaunchKernelGGL(tiles_copy_kernel<false>, dim3((unsigned)n), dim3(256), 0, stream, d_tiles, n, W, H, B, row_begin,
+                           row_end, static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst));
+    }
+    return hipGetLastError();
+}
+
+hipError_t par_launch_background(void* dst, size_t n_px, uint32_t rgba, hipStream_t stream) {
+    if (n_px == 0) return hipSuccess;
+    size_t blocks = (n_px / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(background_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<uint32_t*>(dst), n_px,
+                       rgba);
     return hipGetLastError();
 }
 

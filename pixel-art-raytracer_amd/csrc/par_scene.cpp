@@ -177,6 +177,49 @@ void par_debug_line(const par_params* p, const par_pixel* pick, int mouse_x, con
 }
 
 // Row blocks of a frame sharded over several GPUs: cut at bin rows, the bin rows dealt evenly.
+// The screen columns the entities reach: cull and bin ranges of alt:212-240 (x and y only; the z range decides how
+// many bins of a column an entity lands in, not whether it reaches the column -- an entity whose z range is empty
+// reaches none).
+int par_scene_tiles(const par_params* p, const par_aabb* aabbs, int n, int32_t* tiles, int capacity) {
+    int gx, gy, gz;
+    if (!p || n < 0 || (n > 0 && !aabbs) || capacity < 0 || (capacity > 0 && !tiles) ||
+        par_grid_dims(p, &gx, &gy, &gz) != PAR_OK) {
+        return -PAR_ERR_INVALID_ARG;
+    }
+    if (gx > 65535 || gy > 32767) return -PAR_ERR_UNSUPPORTED;
+    const int W = p->width, H = p->height, L = p->length, B = p->bin_size;
+    unsigned char* reached = static_cast<unsigned char*>(std::calloc((size_t)gx * gy, 1));
+    if (!reached) return -PAR_ERR_OOM;
+    for (int i = 0; i < n; i++) {
+        const par_aabb& a = aabbs[i];
+        const int minx = a.px, miny = a.py, minz = a.pz;
+        const int maxx = minx + a.ex, maxy = miny + a.ey, maxz = minz + a.ez;
+        if ((maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) || (maxz < -a.ez - B) ||
+            (minz > L + B)) {
+            continue;  // alt:212-219
+        }
+        const int x0 = minx / B > 0 ? minx / B : 0, y0 = (H - maxy - maxz) / B > 0 ? (H - maxy - maxz) / B : 0;
+        const int z0 = minz / B > 0 ? minz / B : 0;
+        const int x1 = (maxx + B - 1) / B < gx ? (maxx + B - 1) / B : gx;
+        const int y1 = (H - miny - minz + B - 1) / B < gy ? (H - miny - minz + B - 1) / B : gy;
+        const int z1 = (maxz + B - 1) / B < gz ? (maxz + B - 1) / B : gz;  // alt:222-240
+        if (z1 <= z0) continue;
+        for (int y = y0; y < y1; y++) {
+            for (int x = x0; x < x1; x++) reached[(size_t)y * gx + x] = 1;
+        }
+    }
+    int count = 0;
+    for (int y = 0; y < gy; y++) {
+        for (int x = 0; x < gx; x++) {
+            if (!reached[(size_t)y * gx + x]) continue;
+            if (count < capacity) tiles[count] = x | (y << 16);
+            count++;
+        }
+    }
+    std::free(reached);
+    return count;
+}
+
 void par_row_block(int rank, int ranks, int height, int bin_size, int* begin, int* end) {
     if (ranks < 1) ranks = 1;
     if (bin_size < 1) bin_size = 1;

@@ -17,6 +17,7 @@ def main():
     height = int(sys.argv[1])
     width = int(sys.argv[2])
     out_path = sys.argv[3]
+    mode = sys.argv[4] if len(sys.argv) > 4 else "blocks"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     par = importlib.import_module("pixel-art-raytracer_amd")
@@ -31,13 +32,24 @@ def main():
     grid = o.bin(params, aabbs)
     gbuf, _ = o.primary(params, grid, sprite, rows=(r0, r1))
     fb, _, _ = o.shade(params, grid, gbuf, light, rows=(r0, r1))
-    g = sharding.FrameGather(height, width * 4, torch.uint8, torch.device("cpu"), world, rank)
-    block = g.block_buffer(torch.uint8, torch.device("cpu"))
     mine = torch.from_numpy(fb[r0 * width:r1 * width].view(np.uint8).copy())
-    block[:mine.numel()] = mine
-    work = g.gather(block, async_op=True)
-    work.wait()
-    g.unpack()
+    if mode == "tiles":
+        # only the tiles that can show a primitive travel; the root writes the background itself (TileGather)
+        g = sharding.TileGather(params, aabbs, "cpu", world, rank)
+        block = g.block_buffer()
+        block[:mine.numel()] = mine
+        packed = g.packed_buffer()
+        g.pack(block, packed)
+        g.exchange(packed, async_op=True).wait()
+        g.assemble()
+        assert sum(g.counts) == len(g.tiles) and all(c >= 0 for c in g.counts)
+    else:
+        g = sharding.FrameGather(height, width * 4, torch.uint8, torch.device("cpu"), world, rank)
+        block = g.block_buffer(torch.uint8, torch.device("cpu"))
+        block[:mine.numel()] = mine
+        work = g.gather(block, async_op=True)
+        work.wait()
+        g.unpack()
     if rank == 0:
         full = o.render(params, aabbs, sprite, light, planes=("fb",))["fb"].view(np.uint8)
         ok = bool(np.array_equal(g.frame.numpy(), full))

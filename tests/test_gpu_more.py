@@ -1,5 +1,7 @@
 """GPU parity, second batch: hipGraph replay with moving primitives (BASELINE config 5), the paths that leave the
 wave kernel (column records that overflow, shadow rays that start in unoccupied bins), mouse pick."""
+import os
+
 import numpy as np
 import pytest
 
@@ -463,8 +465,8 @@ def test_config1_default_scene_128(par, oracle, sprite, T):
         assert_planes_equal(r.render(ALL), exp, ALL, "128x128 graybox")
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_bench_multi_rank_control_flow(world):
+@pytest.mark.parametrize("world,assemble", [(2, "tiles"), (3, "tiles"), (3, "blocks"), (2, "none")])
+def test_bench_multi_rank_control_flow(world, assemble):
     """bench.py's N > 1 path (row blocks, frames in flight, per-frame gather, verification of the assembled frame)
     with `world` ranks sharing the one GPU of the test box. RCCL cannot run several ranks on one device, so the
     exchange goes through gloo here; everything else is the code the 8-GPU run executes."""
@@ -480,7 +482,7 @@ def test_bench_multi_rank_control_flow(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
            "--gpus", str(world), "--steps", "12", "--warmup", "3", "--blocks", "3", "--backend", "gloo", "--share-gpu",
-           "--size", "1000" if world == 3 else "1024", "--no-cpu-baseline"]
+           "--size", "1000" if world == 3 else "1024", "--no-cpu-baseline", "--assemble", assemble]
     # PAR_BENCH_RAMP_SKEW: the ranks' clocks WANT different numbers of untimed ramp iterations (each holds
     # collectives); the job only ends if they agree on one number all the same
     p = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300,
@@ -493,8 +495,64 @@ def test_bench_multi_rank_control_flow(world):
     ramp = d["multi_gpu"]["ramp_iterations"]
     assert len(ramp) == world and len(set(ramp)) == 1 and ramp[0] >= 1, ramp  # every rank ran the same number
     mg = d["multi_gpu"]
-    assert len(mg["ranks_seen"]) == world and mg["render_ms"] > 0 and mg["gather_ms"] > 0
-    assert mg["gather_bytes_per_rank"] > 0 and d["ms_per_step_spread"]["blocks"] == 3
+    assert len(mg["ranks_seen"]) == world and mg["render_ms"] > 0 and mg["assemble"] == assemble
+    assert d["ms_per_step_spread"]["blocks"] == 3
+    if assemble == "none":
+        assert mg["gather_ms"] == 0 and mg["gather_bytes_per_rank"] == 0
+    else:
+        assert mg["gather_ms"] > 0 and mg["gather_bytes_per_rank"] > 0
+    if assemble == "tiles":
+        t = mg["tiles"]
+        assert 0 < t["total"] <= t["of"] and sum(t["per_rank"]) == t["total"] and len(t["per_rank"]) == world
+        assert t["bytes_to_rank0"] < 4 * d_size(d) ** 2  # less than the whole frame travels
+
+
+def d_size(d):
+    """The view size of a bench line (its metric names it)."""
+    return int(d["metric"].split(" at ")[1].split("x")[0])
+
+
+def test_eight_row_blocks_and_their_tiles_assemble_the_headline_frame(par, oracle, sprite, T):
+    """The partition an 8-GPU run of the headline uses, on one GPU: the eight blocks par_row_block(r, 8, 4096, 40)
+    rendered one by one (a) concatenate to the whole-frame render, which equals the oracle; (b) packed into the tiles
+    that can show a primitive (par_scene_tiles / par_tiles_pack) and assembled on a background-filled frame
+    (par_background_fill / par_tiles_unpack) give the same frame -- what rank 0 of the sharded run does."""
+    import importlib
+    import torch
+    sharding = importlib.import_module("pixel-art-raytracer_amd.sharding")
+    w = h = l = 4096
+    params = T.default_params(w, h, l)
+    aabbs, light = par.scene_synthetic(1024, w, h, l, 12345)
+    blocks = [sharding.row_block(r, 8, h, params.bin_size) for r in range(8)]
+    assert blocks == [(0, 480), (480, 1000), (1000, 1520), (1520, 2040), (2040, 2560), (2560, 3080), (3080, 3600), (3600, 4096)]
+    tiles = par.scene_tiles(params, aabbs)
+    assert 0 < len(tiles) < np.prod(params.grid_dims()[:2]) // 2     # a sparse frame: most tiles never travel
+    dev = torch.device("cuda", 0)
+    d_tiles = torch.from_numpy(tiles.copy()).to(dev)
+    slot = params.bin_size * params.bin_size * 4
+    inbox = torch.zeros(len(tiles) * slot, dtype=torch.uint8, device=dev)
+    frame = torch.full((h * w * 4,), 7, dtype=torch.uint8, device=dev)
+    by = tiles >> 16
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        whole = r.render(("fb", "palidx"))
+        parts = []
+        for (b, e) in blocks:
+            blk = torch.zeros((e - b) * w * 4, dtype=torch.uint8, device=dev)
+            r.render_device({"fb": blk.data_ptr()}, rows=(b, e))
+            torch.cuda.synchronize()
+            parts.append(blk.cpu().numpy())
+            first = int(np.searchsorted(by, b // params.bin_size)); end = int(np.searchsorted(by, -(-e // params.bin_size)))
+            par.tiles_pack(params, d_tiles.data_ptr() + 4 * first, end - first, blk.data_ptr(), (b, e),
+                           inbox.data_ptr() + first * slot)
+        par.background_fill(params, frame.data_ptr(), h)
+        par.tiles_unpack(params, d_tiles.data_ptr(), len(tiles), inbox.data_ptr(), frame.data_ptr())
+        torch.cuda.synchronize()
+    whole_fb = whole["fb"].view(np.uint8)
+    assert np.array_equal(np.concatenate(parts), whole_fb)
+    assert np.array_equal(frame.cpu().numpy(), whole_fb)
+    exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb", "palidx"))
+    assert whole["fb"].tobytes() == exp["fb"].tobytes() and whole["palidx"].tobytes() == exp["palidx"].tobytes()
 
 
 def test_host_demo_gif(par, oracle, T, tmp_path):
@@ -741,22 +799,28 @@ def test_cpp_pipeline_host(par):
         assert line["host"] == "C++" and line["frames_per_s"] > 0
 
 
-def test_cpp_ranks_host_gathers_over_rccl(par, tmp_path):
-    """The sharded-frame loop in host C++ (par_ranks): one process per GPU, row blocks cut at bin rows, ONE ncclGather
-    per frame enqueued behind the render on the frame's stream. A one-GPU box can run it with one rank (RCCL's gather
-    of the only block), which still executes the whole per-frame path: communicator set-up from the id file, render
-    into the block, gather, assembled frame equal to the whole-frame render (--check)."""
+@pytest.mark.parametrize("gather", ["tiles", "blocks", "none"])
+def test_cpp_ranks_host_gathers_over_rccl(par, tmp_path, gather):
+    """The sharded-frame loop in host C++ (par_ranks): one process per GPU, row blocks cut at bin rows, the frame's
+    exchange enqueued behind the render on the frame's stream: the tiles that can show a primitive to rank 0, which
+    writes the background itself (tiles), ONE ncclGather of the blocks (blocks), or nothing (none). A one-GPU box can
+    run it with one rank, which still executes the whole per-frame path: communicator set-up from the id file, render
+    into the block, pack / background / unpack (or RCCL's gather of the only block), assembled frame equal to the
+    whole-frame render (--check)."""
     import json
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(par.LIB_PATH), "par_ranks")
     assert os.path.exists(exe), "build with make -C pixel-art-raytracer_amd/csrc"
     p = subprocess.run([exe, "--ranks", "1", "--rank", "0", "--id-file", str(tmp_path / "rccl_ids"), "--size", "1024",
-                        "--prims", "300", "--frames", "80", "--inflight", "3", "--check"],
+                        "--prims", "300", "--frames", "80", "--inflight", "3", "--gather", gather, "--check"],
                        capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0 and "check: ok" in p.stdout, p.stdout + p.stderr
+    assert p.returncode == 0 and f"check (rank 0, gather {gather}): ok" in p.stdout, p.stdout + p.stderr
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["host"] == "C++ ranks" and line["ranks"] == 1 and line["gather_bytes_per_rank"] == 1024 * 1024 * 4
+    assert line["host"] == "C++ ranks" and line["ranks"] == 1 and line["gather"] == gather
+    assert line["bytes_to_rank0_per_frame"] == 0  # (one rank: nothing travels)
+    if gather == "tiles":
+        assert 0 < line["tiles"] < 26 * 26
 
 
 def test_one_launch_hash_build_equals_two_launches(par, oracle, sprite, T):

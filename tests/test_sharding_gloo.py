@@ -37,13 +37,38 @@ def test_row_blocks_partition():
                                                                    (2040, 2560), (2560, 3080), (3080, 3600), (3600, 4096)]
 
 
-@pytest.mark.parametrize("world,height", [(2, 160), (3, 200), (2, 320)])
-def test_gather_assembles_the_frame(tmp_path, world, height):
+@pytest.mark.parametrize("world,height,mode", [(2, 160, "blocks"), (3, 200, "blocks"), (2, 320, "blocks"),
+                                               (2, 320, "tiles"), (3, 200, "tiles")])
+def test_gather_assembles_the_frame(tmp_path, world, height, mode):
+    """mode "blocks": whole row blocks gathered (FrameGather); "tiles": only the tiles that can show a primitive
+    travel and the root writes the background itself (TileGather)."""
     out = tmp_path / "result.txt"
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "tests", "_gloo_worker.py"), str(height), "240", str(out)]
+           os.path.join(ROOT, "tests", "_gloo_worker.py"), str(height), "240", str(out), mode]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     assert out.read_text() == "ok"
+
+
+def test_scene_tiles_cover_every_covered_pixel():
+    """par_scene_tiles (host arithmetic): sorted by bin row, and a superset of the tiles in which the oracle covers a
+    pixel -- what makes it safe to let only those tiles travel."""
+    import numpy as np
+    par = importlib.import_module("pixel-art-raytracer_amd")
+    from oracle.oracle import Oracle
+    T = par.types
+    o = Oracle()
+    for (w, h, l, n, seed, b) in [(240, 200, 200, 60, 5, 40), (333, 170, 90, 150, 9, 16), (128, 128, 128, 3, 1, 64)]:
+        params = T.default_params(w, h, l, b)
+        aabbs, light = par.scene_synthetic(n, w, h, l, seed)
+        tiles = par.scene_tiles(params, aabbs)
+        keys = (tiles >> 16) * 65536 + (tiles & 0xFFFF)
+        assert np.all(np.diff(keys) > 0)
+        pal = o.render(params, aabbs, par.tile_floor(), light, planes=("palidx",))["palidx"].reshape(h, w)
+        ys, xs = np.nonzero(pal != T.PALIDX_BACKGROUND)
+        covered = set(zip((xs // b).tolist(), (ys // b).tolist()))
+        listed = set(zip((tiles & 0xFFFF).tolist(), (tiles >> 16).tolist()))
+        assert covered <= listed
+    assert len(par.scene_tiles(T.default_params(), T.make_aabbs([]))) == 0
