@@ -39,6 +39,12 @@ struct par_context {
     int64_t total_pairs = 0;
     int64_t total_cols = 0;        // >= the occupied columns of the frame
     int64_t total_items = 0;       // >= the render work items (64-pixel chunks) of the frame, see footprint_of
+    // The same three from the entities' EXTENTS alone (bound_of: wherever an entity stands it reaches no more): what
+    // pools and lists are sized by, and what a frame's launches are sized by while the exact bookkeeping above is
+    // stale -- par_update_aabbs_async does not keep it (a moving scene would pay the cull and range arithmetic of
+    // every moved entity on the host, every frame); the next blocking call brings it up to date (refresh_exact).
+    int64_t bound_pairs = 0, bound_cols = 0, bound_items = 0;
+    bool exact_stale = false;
     std::vector<int32_t> h_colpairs;  // (entity, bin) pairs per screen column (>= its occupied bins, >= its entries)
     int64_t cols_over = 0;            // columns with more pairs than a column record is sure to hold
     // 64-pixel chunks of the entities' sprite rectangles per screen column (what the column kernel adds up, over the
@@ -165,6 +171,19 @@ par_footprint footprint_of(const par_context* c, const par_aabb& a) {
     return f;
 }
 
+// What an entity of these extents can cause at most, wherever it stands: an interval of length d meets at most
+// ceil(d / B) + 1 bins of width B (alt:222-240), its sprite rectangle is ex x (ey + ez) pixels (alt:310-317).
+struct par_bound {
+    int64_t pairs, cols, items;
+};
+par_bound bound_of(const par_context* c, const par_aabb& a) {
+    const int B = c->params.bin_size;
+    const int64_t nx = std::min<int64_t>(c->gx, ((int)a.ex + B - 1) / B + 1);
+    const int64_t ny = std::min<int64_t>(c->gy, ((int)a.ey + (int)a.ez + B - 1) / B + 1);
+    const int64_t nz = std::min<int64_t>(c->gz, ((int)a.ez + B - 1) / B + 1);
+    return par_bound{nx * ny * nz, nx * ny, (int64_t)a.ex * ((int)a.ey + (int)a.ez) / 64 + nx * ny};
+}
+
 // Adds (sign = +1) or removes (-1) a footprint's pairs in the per-column histogram. A column whose pairs exceed
 // PAR_COL_NB (<= PAR_COL_ENT) may overflow its record; while there is none, no column can, and the frame needs no
 // launch for the overflow list.
@@ -214,7 +233,23 @@ void plan_update(const par_context* c, const par_aabb* aabbs, int first, int n, 
     }
 }
 
+// The bound totals after aabbs[first, first + n) replace the entities there (extents rarely change: then nothing does).
+void bounds_after(const par_context* c, const par_aabb* aabbs, int first, int n, par_bound* total) {
+    *total = par_bound{c->bound_pairs, c->bound_cols, c->bound_items};
+    for (int i = 0; i < n; i++) {
+        const par_aabb& old = c->h_aabbs[(size_t)(first + i)];
+        if (old.ex == aabbs[i].ex && old.ey == aabbs[i].ey && old.ez == aabbs[i].ez) continue;
+        const par_bound o = bound_of(c, old), b = bound_of(c, aabbs[i]);
+        total->pairs += b.pairs - o.pairs;
+        total->cols += b.cols - o.cols;
+        total->items += b.items - o.items;
+    }
+}
+
 void commit_update(par_context* c, const par_aabb* aabbs, int first, int n, const par_update_plan& plan) {
+    par_bound bt;
+    bounds_after(c, aabbs, first, n, &bt);
+    c->bound_pairs = bt.pairs; c->bound_cols = bt.cols; c->bound_items = bt.items;
     for (int i = 0; i < n; i++) {
         par_footprint& slot = c->h_fp[(size_t)(first + i)];
         col_hist(c, slot, -1);
@@ -225,6 +260,26 @@ void commit_update(par_context* c, const par_aabb* aabbs, int first, int n, cons
     c->total_pairs = plan.pairs;
     c->total_cols = plan.cols;
     c->total_items = plan.items;
+}
+
+// The exact bookkeeping (footprints, totals, per-column histograms) from the host's copy of the AABBs, after
+// asynchronous updates left it stale.
+void refresh_exact(par_context* c) {
+    if (!c->exact_stale) return;
+    c->h_colpairs.assign((size_t)c->gx * c->gy, 0);
+    c->h_colchunks.assign((size_t)c->gx * c->gy, 0);
+    c->cols_over = 0;
+    c->cols_tileable = 0;
+    c->total_pairs = c->total_cols = c->total_items = 0;
+    for (int i = 0; i < c->n_entities; i++) {
+        const par_footprint f = footprint_of(c, c->h_aabbs[(size_t)i]);
+        c->h_fp[(size_t)i] = f;
+        col_hist(c, f, +1);
+        c->total_pairs += f.pairs();
+        c->total_cols += f.cols();
+        c->total_items += f.items;
+    }
+    c->exact_stale = false;
 }
 
 bool extent_ok(const par_aabb& a) {
@@ -465,7 +520,8 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // The overflow list is empty for sure while no column has more pairs than a record holds (a captured graph also
     // serves later frames, whose columns nobody knows yet): then the frame has no launch for it, and the column
     // kernel flags the frame should a column overflow all the same.
-    const bool may_overflow = graph_mode || ctx->cols_over > 0 || r.dense || (ev && !(flags & PAR_RENDER_TIMED_AS_LAUNCHED));
+    const bool may_overflow = graph_mode || ctx->cols_over > 0 || ctx->exact_stale || r.dense ||
+                              (ev && !(flags & PAR_RENDER_TIMED_AS_LAUNCHED));
     r.overflow_launched = may_overflow ? 1 : 0;
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
         PAR_HIP(hipMemsetAsync(ctx->d_ray_counter, 0, sizeof(unsigned long long), stream));
@@ -483,7 +539,8 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     rf.out.lit = nullptr;
     // A captured graph must also hold for later frames, whose pair count is unknown at capture time: the bound is
     // what par_graph_stage accepts (graph_pair_bound); beyond it the caller captures again.
-    const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : ctx->total_pairs;
+    const bool stale = ctx->exact_stale;  // (asynchronous updates since the last blocking call: extents-only bounds)
+    const int64_t pair_bound = graph_mode ? ctx->graph_pair_bound : (stale ? ctx->bound_pairs : ctx->total_pairs);
     // small scenes build the hash in one launch, large ones in two (timed runs keep the kernels apart)
     static const bool two_env = [] { const char* e = std::getenv("PAR_BUILD_TWO_LAUNCHES"); return e && e[0] == '1'; }();
     const bool two_launches = two_env || (flags & (1u << 23));  // bit 23 (tests): insert and resolve as two launches
@@ -497,7 +554,7 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     }
     if (ev) PAR_HIP(hipEventRecord(ev[5], stream));  // (behind the hash build)
     // occupied columns <= the columns the entities reach one by one (<= their (entity, bin) pairs)
-    const int64_t col_bound = graph_mode ? pair_bound : ctx->total_cols;
+    const int64_t col_bound = graph_mode ? pair_bound : (stale ? ctx->bound_cols : ctx->total_cols);
     if (ride) {
         PAR_HIP(par_launch_columns_fill(ctx->grid, rf, col_bound, plan, stream));
     } else {
@@ -520,7 +577,8 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     if (ev) PAR_HIP(hipEventRecord(ev[3], stream));
     // work items <= what the entities can cause one by one, and <= every column of the rendered rows as a whole tile
     const int64_t item_cap_rows = max_items(ctx) / ctx->gy * (r.by_hi - r.by_lo + 1);
-    const int64_t item_bound = std::min(graph_mode ? ctx->graph_item_bound : ctx->total_items, item_cap_rows);
+    const int64_t item_bound = std::min(graph_mode ? ctx->graph_item_bound : (stale ? ctx->bound_items : ctx->total_items),
+                                        item_cap_rows);
     bool both = false;
     if (!apart) {  // small frames: one launch for both render kernels
         const hipError_t e = par_launch_render_both(ctx->grid, r, col_bound, item_bound, may_overflow, stream);
@@ -775,9 +833,16 @@ static int par_set_entities_impl(par_context* ctx, const par_aabb* aabbs, const 
         total_cols += f.cols();
         total_items += f.items;
     }
-    int rc = ensure_pool(ctx, total);
+    // (pools and lists by what the extents allow: they then hold wherever the entities move)
+    par_bound bt{0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const par_bound b = bound_of(ctx, aabbs[i]);
+        bt.pairs += b.pairs; bt.cols += b.cols; bt.items += b.items;
+    }
+    if (bt.pairs > 0x3FFFFFFF) return fail(ctx, PAR_ERR_UNSUPPORTED, "too many (entity, bin) pairs");
+    int rc = ensure_pool(ctx, std::max(total, bt.pairs));
     if (rc != PAR_OK) return rc;
-    rc = ensure_items(ctx, total_items, total_cols);
+    rc = ensure_items(ctx, std::max(total_items, bt.items), std::max(total_cols, bt.cols));
     if (rc != PAR_OK) return rc;
     if (n > ctx->aabb_capacity) {
         if (ctx->d_aabbs) PAR_HIP(hipFree(ctx->d_aabbs));
@@ -803,6 +868,8 @@ static int par_set_entities_impl(par_context* ctx, const par_aabb* aabbs, const 
     ctx->total_pairs = total;
     ctx->total_cols = total_cols;
     ctx->total_items = total_items;
+    ctx->bound_pairs = bt.pairs; ctx->bound_cols = bt.cols; ctx->bound_items = bt.items;
+    ctx->exact_stale = false;
     ctx->n_entities = n;
     ctx->max_sprite_id = max_id;
     ctx->have_entities = true;
@@ -858,12 +925,15 @@ static int par_update_aabbs_impl(par_context* ctx, const par_aabb* aabbs, int fi
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
+    refresh_exact(ctx);  // (asynchronous updates may have left the exact bookkeeping behind)
     par_update_plan plan;
     plan_update(ctx, aabbs, first, n, &plan);
+    par_bound bt;
+    bounds_after(ctx, aabbs, first, n, &bt);
     PAR_HIP(hipSetDevice(ctx->device));
-    int rc = ensure_pool(ctx, plan.pairs);
+    int rc = ensure_pool(ctx, std::max(plan.pairs, bt.pairs));
     if (rc != PAR_OK) return rc;
-    rc = ensure_items(ctx, plan.items, plan.cols);
+    rc = ensure_items(ctx, std::max(plan.items, bt.items), std::max(plan.cols, bt.cols));
     if (rc != PAR_OK) return rc;
     // a frame enqueued asynchronously by par_render_device may still be reading the AABBs: wait for it
     if (ctx->has_last_stream) PAR_HIP(hipStreamSynchronize(ctx->last_stream));
@@ -886,12 +956,15 @@ static int par_update_aabbs_async_impl(par_context* ctx, const par_aabb* aabbs, 
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    par_update_plan plan;
-    plan_update(ctx, aabbs, first, n, &plan);
+    // No cull and range arithmetic here (it cost a moving scene more host time per frame than its launches): the
+    // frame's launches are sized by what the EXTENTS allow (bound_of) until a blocking call refreshes the exact
+    // bookkeeping, and the frame gets its launch for the overflow list whatever the columns hold.
+    par_bound bt;
+    bounds_after(ctx, aabbs, first, n, &bt);
     PAR_HIP(hipSetDevice(ctx->device));
-    // the node pool and the item list grow rarely; that path frees device memory and has to wait for everything in
-    // flight
-    if (plan.pairs > ctx->grid.capacity || !items_fit(ctx, plan.items, plan.cols)) {
+    // the node pool and the item list grow rarely (only when extents grow); that path frees device memory and has to
+    // wait for everything in flight
+    if (bt.pairs > ctx->grid.capacity || !items_fit(ctx, bt.items, bt.cols)) {
         return par_update_aabbs(ctx, aabbs, first, n);
     }
     // frames enqueued on another stream are not ordered with this copy: wait for them
@@ -914,7 +987,9 @@ static int par_update_aabbs_async_impl(par_context* ctx, const par_aabb* aabbs, 
     PAR_HIP(hipEventRecord(ctx->ev_update, stream));
     ctx->ev_update_pending = true;
     ctx->update_stream = stream;
-    commit_update(ctx, aabbs, first, n, plan);
+    ctx->bound_pairs = bt.pairs; ctx->bound_cols = bt.cols; ctx->bound_items = bt.items;
+    std::memcpy(ctx->h_aabbs.data() + first, aabbs, (size_t)n * sizeof(par_aabb));
+    ctx->exact_stale = true;
     mark_staged(ctx, first, n);  // (a captured graph uploads the scene from its staging area)
     return PAR_OK;
 }
@@ -992,6 +1067,7 @@ static int par_graph_capture_impl(par_context* ctx, void* stream_v, int row_begi
     PAR_HIP(hipSetDevice(ctx->device));
     PAR_HIP(hipDeviceSynchronize());
     drop_graphs(ctx);
+    refresh_exact(ctx);
     // Head-room for moving primitives: pair counts of later frames are only bounded by the pool.
     ctx->graph_pair_bound = ctx->total_pairs * 2 + 4096;
     rc = ensure_pool(ctx, ctx->graph_pair_bound);
@@ -1050,6 +1126,7 @@ static int par_graph_stage_impl(par_context* ctx, const par_aabb* aabbs, int fir
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
+    refresh_exact(ctx);
     par_update_plan plan;
     plan_update(ctx, aabbs, first, n, &plan);
     if (plan.pairs > ctx->graph_pair_bound || plan.pairs > ctx->grid.capacity) {
@@ -1064,6 +1141,7 @@ static int par_graph_stage_impl(par_context* ctx, const par_aabb* aabbs, int fir
 static int par_graph_launch_impl(par_context* ctx, void* stream) {
     if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
     // (the scene may also have been changed by par_update_aabbs[_async]: same limit as par_graph_stage)
+    refresh_exact(ctx);
     if (ctx->total_pairs > ctx->graph_pair_bound) {
         return fail(ctx, PAR_ERR_UNSUPPORTED, "the scene exceeds what the captured graph was sized for; capture again");
     }
