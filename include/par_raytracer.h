@@ -80,7 +80,8 @@ typedef struct par_frame_stats {
     int64_t overflow_columns; /* ... of which did not fit a column record (rendered straight from the hash) */
     float ms_bin;            /* device time of the hash build + column kernels of the last timed render, else -1 */
     float ms_fill;           /* device time of the background fill kernel of the last timed render, else -1 */
-    float ms_render;         /* device time of the render kernel (render_wave_kernel) of the last timed render, else -1 */
+    float ms_render;         /* device time of the render kernels (render_items_kernel, and render_tiles_kernel in a
+                              * dense frame) of the last timed render, else -1 */
     float ms_overflow;       /* device time of the overflow-column kernel of the last timed render, else -1 */
     float ms_launch[4];      /* PAR_RENDER_TIMED_AS_LAUNCHED: device time of the frame's launches as a production frame
                               * makes them: [0] hash build (+ its share of the fill), [1] column records (+ the rest of the
@@ -118,7 +119,10 @@ int par_set_entities_ref_layout(par_context* ctx, const par_aabb* aabbs, const p
 int par_update_aabbs(par_context* ctx, const par_aabb* aabbs, int first, int n);
 /* The same without blocking: the new AABBs are copied to the device in `stream` order, i.e. after the frames already
  * enqueued on `stream` and before the next one. `stream` must be the stream this context's frames are rendered on
- * (par_render_device); `aabbs` may be reused as soon as the call returns. For a render loop with frames in flight. */
+ * (par_render_device); `aabbs` may be reused as soon as the call returns. For a render loop with frames in flight:
+ * the call does no cull or bin-range arithmetic on the host (the frames that follow size their launches by what the
+ * entities' extents allow wherever they stand, and always carry the launch for overflowed columns), until a blocking
+ * call (par_update_aabbs, par_set_entities, the graph calls) brings the exact bookkeeping up to date. */
 int par_update_aabbs_async(par_context* ctx, const par_aabb* aabbs, int first, int n, void* stream);
 /* lights[0] (alt:712-714, 729-732: the only light the reference reads). */
 int par_set_light(par_context* ctx, const par_light* light);

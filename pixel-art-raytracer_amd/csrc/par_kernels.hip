@@ -1,19 +1,25 @@
 // par_kernels.hip — hand-written HIP kernels for gfx950 (MI355X / CDNA4).
 //
-// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is five launches:
-//   insert_fill_kernel      bin_insert_body   } memset alt:690 + count_entities_in_bins alt:195-269, parallel and
-//   resolve_fill_kernel     bin_resolve_body  }   deterministic (+ which screen columns show any primitive)
+// One frame of the reference's render call (alt = src/alternative.cpp, spr = src/sprites.hpp) is three launches
+// (four for a dense frame), each a latency chain the next depends on:
+//   build_fill_kernel       bin_insert_body, a barrier among the build workgroups, bin_resolve_body: memset alt:690 +
+//                           count_entities_in_bins alt:195-269, parallel and deterministic (+ which screen columns
+//                           show any primitive). Scenes beyond 16 384 entities / 65 536 (entity, bin) pairs take the
+//                           same bodies as two launches (insert_fill_kernel, resolve_fill_kernel)
 //   columns_fill_kernel     columns_wave: per occupied column its compact slot list and the bin walks of
 //                           trace_hash_for_light (alt:399-500; they depend on the start bin only) -> one record,
-//                           and one work item per 64-pixel chunk of the column's visit
+//                           and the column's work items: one per 64-pixel chunk of an entry-by-entry visit, or one
+//                           per tile_k chunks of a whole-tile visit (dense frames)
 //   render_items_kernel     trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect
 //                           alt:40-83, Vector::normalize spr:28-35, Color::operator* spr:8-16 -- one wavefront
-//                           per work item, from the column records, no workgroup cooperation
-//   render_overflow_kernel  the columns that overflow a record: straight from the hash, walks in-kernel
-//                           (PAR_FORCE_GENERIC=1: every column)
-//   (render_both_kernel     the last two in one launch for small frames, which are bound by their launches)
-// The background fill (alt:281 -> alt:735, pure streaming) has no launch of its own: the first three launches
-// each carry a share of it (extra workgroups running fill_body), sized so that it rides along in their shadow.
+//                           per entry-pass work item, from the column records, no workgroup cooperation
+//   render_tiles_kernel     the same for the whole-tile items (render_tile_item: scalar-loaded entries and walk
+//                           records, lane masks in scalar registers); launched for dense frames only
+//   render_overflow_kernel  the columns that overflow a record: straight from the hash, walks in-kernel; launched
+//                           only when the host cannot rule an overflow out (PAR_FORCE_GENERIC=1: every column)
+//   (render_both_kernel     the render kernels in one launch for small frames, which are bound by their launches)
+// The background fill (alt:281 -> alt:735, pure streaming) has no launch of its own: the first two launches each
+// carry a share of it (extra workgroups running fill_body), sized so that it rides along in their shadow.
 // When other planes are asked for (G-buffer, brightness, lit) or the view is not 8-pixel aligned, the hash
 // kernels run bare (bin_insert_kernel, bin_resolve_kernel, columns_kernel) and fill_kernel / fill_generic_kernel
 // follow; bgline_kernel traces the W distinct background shadow rays when every ray is to be traced.
@@ -353,14 +359,20 @@ __device__ __forceinline__ uint32_t color_scale(uint32_t c, float v) {
 
 // Vector<float>::normalize, spr:28-35 — divides by the L1 length (abs(x) + abs(y)) + abs(z) — and the inverse
 // direction 1 / n (alt:717-719), through the short sequences of par_fastdiv.h when every
-// lane's operands are in the range they are exact on (components that are integers of magnitude <= 65535 — the
-// caller's are differences of integers — and a length >= 1), through the ordinary divisions otherwise (a light on
+// lane's operands are in the range they are exact on (components that are integers of magnitude <= 65535 — checked:
+// the render kernels' are differences of integers, the test hook's may be anything — and a length >= 1), through the
+// ordinary divisions otherwise (a light on
 // the pixel: 0 / 0; sprite depths that throw a pixel far out). Wave-uniform choice: one branch, no divergence.
+// ANY_INPUT: the components may be any floats (the test hook); false: the caller passes converted integers.
+template <bool ANY_INPUT = false>
 __device__ __forceinline__ void normalize_l1_and_inverse(float x, float y, float z, float& nx, float& ny, float& nz,
                                                          float& ix, float& iy, float& iz) {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y), az = __builtin_fabsf(z);
     const float len = ax + ay + az;
-    const bool in_range = ax <= PAR_FASTDIV_MAX_NUM && ay <= PAR_FASTDIV_MAX_NUM && az <= PAR_FASTDIV_MAX_NUM && len >= 1.0f;
+    // (tools/divcheck.hip proves the short sequences for INTEGER numerators: the render kernels' are differences of
+    // integers; the test hook par_debug_units kind 2 takes any floats, which then go through the ordinary divisions)
+    const bool integral = !ANY_INPUT || (x == __builtin_truncf(x) && y == __builtin_truncf(y) && z == __builtin_truncf(z));
+    const bool in_range = integral && ax <= PAR_FASTDIV_MAX_NUM && ay <= PAR_FASTDIV_MAX_NUM && az <= PAR_FASTDIV_MAX_NUM && len >= 1.0f;
     if (__all(in_range)) {
         const float r = __builtin_amdgcn_rcpf(len);
         nx = par_fast_div(x, len, r);
@@ -1058,7 +1070,8 @@ __global__ __launch_bounds__(256) void fill_generic_kernel(par_render_args a, ui
 
 // ------------------------------------------------------------------------------------------------------------
 // Per-lane shadow walk: trace_hash_for_light (alt:399-500) exactly as written, for the rare pixel whose shadow ray
-// starts in a bin that holds no primitive (negative world z, sprite depths outside the box) in render_wave_kernel.
+// starts in a bin that holds no primitive (negative world z, sprite depths outside the box) or whose walk was too
+// long to record, in the render kernels.
 // ------------------------------------------------------------------------------------------------------------
 __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, int sx, int sy,
                                  int sz, const par_frame_dyn& dyn, int self, int ox, int oy, int oz, float ix,
@@ -1397,8 +1410,22 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         asm volatile("" ::"v"(rgba), "v"(bright), "v"(pal_index));
     } else if (valid && hit) {  // (uncovered pixels keep what the fill wrote)
         const size_t o = (size_t)(row - a.row_begin) * W + col;
+#if !defined(PAR_EXP_STORE)
         if (a.out.fb) __builtin_nontemporal_store(color_scale(rgba, bright), reinterpret_cast<uint32_t*>(a.out.fb) + o);
         if (a.out.palidx) __builtin_nontemporal_store((uint8_t)pal_index, a.out.palidx + o);
+#elif PAR_EXP_STORE == 1  // (experiments, tools/debug/variants.sh: plain stores)
+        if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
+        if (a.out.palidx) a.out.palidx[o] = (uint8_t)pal_index;
+#elif PAR_EXP_STORE == 2  // (timing only: no palette-index store)
+        if (a.out.fb) __builtin_nontemporal_store(color_scale(rgba, bright), reinterpret_cast<uint32_t*>(a.out.fb) + o);
+        asm volatile("" ::"v"(pal_index));
+#elif PAR_EXP_STORE == 3  // (timing only: no frame store)
+        asm volatile("" ::"v"(rgba), "v"(bright));
+        if (a.out.palidx) __builtin_nontemporal_store((uint8_t)pal_index, a.out.palidx + o);
+#elif PAR_EXP_STORE == 4  // (plain frame store, streaming palette index)
+        if (a.out.fb) reinterpret_cast<uint32_t*>(a.out.fb)[o] = color_scale(rgba, bright);
+        if (a.out.palidx) __builtin_nontemporal_store((uint8_t)pal_index, a.out.palidx + o);
+#endif
         if (FULL && a.out.brightness) a.out.brightness[o] = bright;
         if (FULL && a.out.lit) a.out.lit[o] = lit_px ? 1 : 0;
         if (FULL && a.out.gbuf) {
@@ -2109,7 +2136,7 @@ __global__ __launch_bounds__(256) void units_kernel(int kind, const void* in_a, 
         const float* v = static_cast<const float*>(in_a) + (size_t)i * 3;
         float* o = static_cast<float*>(out) + (size_t)i * 3;
         float ix, iy, iz;  // (the same function the shading uses: short sequences where they are exact)
-        normalize_l1_and_inverse(v[0], v[1], v[2], o[0], o[1], o[2], ix, iy, iz);
+        normalize_l1_and_inverse<true>(v[0], v[1], v[2], o[0], o[1], o[2], ix, iy, iz);
     }
 }
 
@@ -2349,7 +2376,12 @@ static int64_t item_workgroups(int64_t item_bound) {
 hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, int64_t item_bound,
                              hipStream_t stream) {
     if (item_bound <= 0 || a.dense) return hipSuccess;
-    const dim3 grid((unsigned)item_workgroups(item_bound)), block(PAR_WAVE_NW * 64);
+    // In a dense frame (a.tile_k > 0) most of the bound's chunks become tile items of the other kernel: the entry
+    // kernel gets a modest grid whose wavefronts loop over their shards (16 640 wavefronts that found no item cost a
+    // full-floor frame 10 us of kernel time).
+    int64_t wgs = item_workgroups(item_bound);
+    if (a.tile_k > 0 && wgs > 1024) wgs = 1024;
+    const dim3 grid((unsigned)wgs), block(PAR_WAVE_NW * 64);
     if (a.flags & PAR_DEBUG_FLAGS) {
         hipLaunchKernelGGL((render_items_kernel<true, true, true>), grid, block, 0, stream, g, a);
     } else if (a.sprite_ids || a.out.brightness || a.out.lit || a.out.gbuf) {
