@@ -470,6 +470,7 @@ par_bin_args make_bin_args(const par_context* c, int set, int row_begin, int row
     b.n = c->n_entities;
     b.set = set;
     b.aabbs = c->d_aabbs;
+    b.magic_b = (uint32_t)((1ull << 32) / (uint64_t)c->params.bin_size + 1ull);
     // tests: a build workgroup that never arrives at the one-launch hash build's barrier (PAR_ERR_DEVICE)
     static const bool lose = [] { const char* e = std::getenv("PAR_TEST_LOSE_BUILD_WG"); return e && e[0] == '1'; }();
     b.test_lose_wg = lose ? 1 : 0;

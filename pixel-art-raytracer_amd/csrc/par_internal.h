@@ -170,6 +170,7 @@ struct par_bin_args {
     int32_t by_lo, by_hi;    // bin rows [by_lo, by_hi] the render of this frame touches (column-list filter)
     uint32_t flags;          // render flags (bit 29: debug time stamps)
     int32_t test_lose_wg;    // tests (PAR_TEST_LOSE_BUILD_WG=1): build workgroup 0 never arrives at the barrier
+    uint32_t magic_b;        // floor(n / B) == __umulhi(n, magic_b) for n * B < 2^32 (as par_render_args::magic_b)
     const par_aabb* aabbs;
 };
 

@@ -98,13 +98,37 @@ __device__ __forceinline__ void item_arrived(u32x8& v) {
 #endif
 }
 
+// Inclusive prefix sum over the 64 lanes of a (whole) wavefront, by data-parallel-primitive adds: within each row of
+// 16 lanes by shifts of 1, 2, 4, 8 (zeros shifted in), then the row totals passed on by the two row broadcasts. Six
+// vector instructions and no LDS round trip (a shuffle is a ds_bpermute, a hundred cycles each: the six dependent ones
+// of the textbook scan were a third of a microsecond per scan of a column's wavefront, which makes four or five).
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
-#pragma unroll
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+#else
     for (int d = 1; d < 64; d <<= 1) {
         const int y = __shfl_up(v, d);
         if (lane >= d) v += y;
     }
     return v;
+#endif
+}
+
+// The value of lane `src` (wave-uniform) in every lane: a v_readlane, not a shuffle through the LDS crossbar.
+__device__ __forceinline__ int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+// Trunc-toward-zero division by the bin size through a precomputed reciprocal: exact for |n| * B < 2^32
+// (|n| <= 3 * 32767 here and B <= 320).
+__device__ __forceinline__ int div_bin(int n, uint32_t magic) {
+    const int q = (int)__umulhi((uint32_t)(n < 0 ? -n : n), magic);
+    return n < 0 ? -q : q;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -155,12 +179,15 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
             const bool culled = (maxx < 0) || (minx >= W) || (maxy < 0 - maxz) || (miny >= H - minz + B) ||
                                 (maxz < -box.ez - B) || (minz > L + B);  // alt:212-219
             if (!culled) {
-                const int x0 = max(0, minx / B);                                       // alt:222
-                const int y0 = max(0, (H - maxy - maxz) / B);                          // alt:223-225
-                const int z0 = max(0, minz / B);                                       // alt:226
-                const int nx = max(0, min(g.gx, (maxx + B - 1) / B) - x0);             // alt:228-230
-                const int ny = max(0, min(g.gy, (H - miny - minz + B - 1) / B) - y0);  // alt:231-236
-                const int nz = max(0, min(g.gz, (maxz + B - 1) / B) - z0);             // alt:238-240
+                // (the reference's divisions truncate towards zero: div_bin, a multiplication by the reciprocal of the
+                // bin size; the compiler's sequence for a run-time divisor is some thirty instructions, six times)
+                const uint32_t mb = a.magic_b;
+                const int x0 = max(0, div_bin(minx, mb));                                       // alt:222
+                const int y0 = max(0, div_bin(H - maxy - maxz, mb));                            // alt:223-225
+                const int z0 = max(0, div_bin(minz, mb));                                       // alt:226
+                const int nx = max(0, min(g.gx, div_bin(maxx + B - 1, mb)) - x0);               // alt:228-230
+                const int ny = max(0, min(g.gy, div_bin(H - miny - minz + B - 1, mb)) - y0);    // alt:231-236
+                const int nz = max(0, min(g.gz, div_bin(maxz + B - 1, mb)) - z0);               // alt:238-240
                 k = nx * ny * nz;
                 org = x0 | (y0 << 10) | (z0 << 20);  // grid dimensions are at most 1024 per axis
                 dim = ny | (nz << 11);               // box spans are at most 1024 bins per axis
@@ -168,11 +195,11 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
         }
         const int incl = wave_incl_scan_i(k, lane);
         const int excl = incl - k;
-        const int total = __shfl(incl, 63);
+        const int total = wave_bcast(incl, 63);
         if (total == 0) continue;
         int base = 0;
         if (lane == 0) base = atomicAdd(&g.node_counter[s], total);
-        base = __shfl(base, 0);
+        base = wave_bcast(base, 0);
         for (int p0 = 0; p0 < total; p0 += 64) {  // wave-uniform: every lane takes part in the shuffles below
             const int p = p0 + lane;
             // owner of pair p: the last lane whose exclusive offset is <= p (lanes with k == 0 share their
@@ -188,8 +215,13 @@ __device__ __forceinline__ void bin_insert_body(const par_grid_dev& g, const par
             const int o3 = __shfl(org, lo), d3 = __shfl(dim, lo);
             if (p < total) {
                 const int ny = d3 & 0x7FF, nz = d3 >> 11;
-                const int jz = j % nz, t = j / nz;
-                const int jy = t % ny, jx = t / ny;
+                // j = (jx * ny + jy) * nz + jz. The spans are small (an extent of at most 40 over bins of at least 8: a
+                // handful of bins per axis, j below a few hundred): floor(n / d) = (int)((n + 0.5) * rcp(d)) exactly
+                // (the quotient is at least 0.5 / d from every integer, the reciprocal is good to an ulp; par_strips.h)
+                const int t = (int)(((float)j + 0.5f) * __builtin_amdgcn_rcpf((float)nz));
+                const int jz = j - t * nz;
+                const int jx = (int)(((float)t + 0.5f) * __builtin_amdgcn_rcpf((float)ny));
+                const int jy = t - jx * ny;
                 const int b = flat_index(g.gy, g.gz, (o3 & 0x3FF) + jx, ((o3 >> 10) & 0x3FF) + jy, (o3 >> 20) + jz);
                 const int node = base + p;
                 // the host sizes the pool from the exact pair count and b is in range by construction: belt and braces
@@ -391,22 +423,51 @@ __device__ __forceinline__ void normalize_l1_and_inverse(float x, float y, float
     }
 }
 
-// Trunc-toward-zero division by the bin size through a precomputed reciprocal: exact for |n| * B < 2^32
-// (|n| <= 3 * 32767 here and B <= 320).
-__device__ __forceinline__ int div_bin(int n, uint32_t magic) {
-    const int q = (int)__umulhi((uint32_t)(n < 0 ? -n : n), magic);
-    return n < 0 ? -q : q;
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // wave_walk: ONE wavefront walks from bin (sx, sy, sz) to the light's bin as trace_hash_for_light does
 // (alt:399-500) and stages the slot records of every occupied bin on the way (start bin excluded, alt:471-473) in
-// `stage` (LDS, PAR_BIN_WALK records). Returns their number, or -1 when they do not fit. `chain` is 3 x 65 int16
-// of LDS scratch. The probed bin sequence depends only on the two bins, not on a ray; the reference's result is an
-// OR over the probes, so neither probe order nor duplicates matter.
+// `stage` (LDS, PAR_BIN_WALK records). Returns their number, or -1 when they do not fit. The probed bin sequence
+// depends only on the two bins, not on a ray; the reference's result is an OR over the probes, so neither probe order
+// nor duplicates matter.
+// It runs in rounds of 64 iterations of the reference's loop, lane k taking iteration it0 + k:
+//   - the float accumulation cur += step (alt:436-466) is inherently serial, but every lane can run it: lane k needs
+//     the position after k additions, so all lanes start from the round's first position and add the step under an
+//     EXEC mask that loses its lowest lane at every step (s_lshl_b64 exec, exec, 1): lane k takes part in exactly k
+//     additions. Three register-only additions and one scalar shift per step, the same single-precision sums in the
+//     same order as the reference's, no memory. (Until round 3 one lane per axis added and left every position in
+//     LDS for the others: 3 us per walk, bound by the LDS store path of a CU whose resident wavefronts all did the
+//     same at the same time.)
+//   - the 7 probes of an iteration (alt:438-466) are the corners of the 2x2x2 block spanned by bin(tmp) and
+//     bin(tmp + step), minus bin(tmp) itself; their counts are loaded side by side, the records of the occupied
+//     ones appended to the stage.
 // ------------------------------------------------------------------------------------------------------------
+
+// 16 steps of the accumulation for a whole (64-lane) wavefront: a lane of `lanes` takes part in the first step, and
+// every step the lowest lane still taking part drops out.
+__device__ __forceinline__ void walk_chain_block(float& vx, float& vy, float& vz, float sx, float sy, float sz,
+                                                 uint64_t lanes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "s_mov_b64 exec, %[m0]\n"
+        ".rept 16\n"
+        "v_add_f32 %[x], %[x], %[sx]\n"
+        "v_add_f32 %[y], %[y], %[sy]\n"
+        "v_add_f32 %[z], %[z], %[sz]\n"
+        "s_lshl_b64 exec, exec, 1\n"
+        ".endr\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [x] "+v"(vx), [y] "+v"(vy), [z] "+v"(vz), [sv] "=&s"(saved)
+        : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [m0] "s"(lanes)
+        : "scc");
+#else
+    (void)vx; (void)vy; (void)vz; (void)sx; (void)sy; (void)sz; (void)lanes;
+#endif
+}
+
 __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_slot* slots, const par_frame_dyn& dyn,
-                         int sx, int sy, int sz, int16_t (*chain)[65], par_slot* stage, uint32_t sflags = 0) {
+                         int sx, int sy, int sz, par_slot* stage, uint32_t sflags = 0) {
     const int lane = threadIdx.x & 63;
     const int b0 = flat_index(g.gy, g.gz, sx, sy, sz);  // alt:430
     // alt:406-430
@@ -416,41 +477,28 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
     if (largest < __builtin_fabsf(ddy)) largest = __builtin_fabsf(ddy);
     if (largest < __builtin_fabsf(ddz)) largest = __builtin_fabsf(ddz);
     const int m = (int)largest;  // alt:432
-    const float step_mine = ((lane == 0) ? ddx : ((lane == 1) ? ddy : ddz)) / largest;  // alt:423-425
-    float carry = (lane == 0) ? fsx : ((lane == 1) ? fsy : fsz);
+    const float stx = ddx / largest, sty = ddy / largest, stz = ddz / largest;  // alt:423-425
+    float cx = fsx, cy = fsy, cz = fsz;  // the position after it0 iterations (wave-uniform)
     int n_rec = 0;
     for (int it0 = 0; it0 < m; it0 += 64) {
         const int n_it = min(64, m - it0);
-        if (lane < 3) {  // the float accumulation (alt:436-466) is serial: one lane per axis
-            // Blocks of 16 unrolled steps (a loop with a branch per step costs 2 us per walk; 64 unrolled steps cost
-            // short walks three times what they need): entries past n_it are never read, and a round shorter than
-            // 64 is the walk's last, so the carry is not needed after it either.
-            float v = carry;
-            chain[lane][0] = (int16_t)(int)v;  // alt:468
-            for (int q0 = 0; q0 < n_it; q0 += 16) {
-#pragma unroll
-                for (int k = 1; k <= 16; k++) {
-                    v = v + step_mine;
-                    chain[lane][q0 + k] = (int16_t)(int)v;
-                }
-            }
-            carry = v;
-        }
+        // lane k: the position after it0 + k iterations (alt:436-466: k additions, one after the other)
+        float vx = cx, vy = cy, vz = cz;
+        for (int t0 = 1; t0 < n_it; t0 += 16) walk_chain_block(vx, vy, vz, stx, sty, stz, ~0ull << t0);
+        // ... and after one more: the next lane's position (the same sum), and the next round's start in lane 63
+        const float wx = vx + stx, wy = vy + sty, wz = vz + stz;
+        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wx), 63));
+        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wy), 63));
+        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wz), 63));
         stamp(g, sflags, 2, 5);
-        // written and read by the same wavefront: LDS operations of one wavefront complete in order; keep the
-        // compiler from moving the reads above the writes
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         // lane l takes walk iteration it0 + l: its 7 probes (alt:438-466) are the corners of the 2x2x2 block
-        // spanned by bin(tmp) and bin(tmp + step), minus bin(tmp) itself
+        // spanned by bin(tmp) and bin(tmp + step), minus bin(tmp) itself (alt:468: truncation; bins fit 16 bits)
         int idx[7], cnt[7];
         int mine = 0;
         {
-            const int li = min(lane, n_it - 1);
-            const int ax = chain[0][li], ay = chain[1][li], az = chain[2][li];
-            const int qx = chain[0][li + 1], qy = chain[1][li + 1], qz = chain[2][li + 1];
+            const int ax = (int)(int16_t)(int)vx, ay = (int)(int16_t)(int)vy, az = (int)(int16_t)(int)vz;
+            const int qx = (int)(int16_t)(int)wx, qy = (int)(int16_t)(int)wy, qz = (int)(int16_t)(int)wz;
             bool ok[7];
 #pragma unroll
             for (int q = 0; q < 7; q++) {
@@ -473,9 +521,8 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
                 mine += cnt[q];
             }
         }
-        __builtin_amdgcn_wave_barrier();
         const int incl = wave_incl_scan_i(mine, lane);
-        const int wave_total = __shfl(incl, 63);
+        const int wave_total = wave_bcast(incl, 63);
         stamp(g, sflags, 2, 6);
         if (n_rec + wave_total > PAR_BIN_WALK) return -1;
         int o = n_rec + incl - mine;
@@ -489,6 +536,14 @@ __device__ int wave_walk(const par_grid_dev& g, const uint8_t* count, const par_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     return n_rec;
+}
+
+// LDS written and read by the same wavefront: its LDS operations complete in order; keep the compiler from moving
+// reads above writes.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -512,17 +567,7 @@ struct ColWave {  // LDS of one wavefront
     par_slot entries[PAR_COL_ENT];
     int16_t ebz[PAR_COL_ENT];
     par_slot stage[PAR_BIN_WALK];  // the records of the walk being done
-    int16_t chain[3][65];
-    int16_t pad_;
 };
-
-// LDS written and read by the same wavefront: its LDS operations complete in order; keep the compiler from moving
-// reads above writes.
-__device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // The box of chunk `c` of a tile visit (strip order, par_strips.h), in tile coordinates: the rows and columns of its
 // first and last pixel when both lie in one strip, the whole rectangle otherwise. `row_off`: the visit's first row
@@ -589,7 +634,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
         if (!a.trace_bg || bx >= g.gx || role != 0) return;
         const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
         // world (x, 0, 0): ray_bin = (x / B, (H - 0 - 0) / B, 0), alt:724-727
-        const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, a.H / a.B, 0, sm.chain, sm.stage);
+        const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, a.H / a.B, 0, sm.stage);
         par_bgwalk* out = g.bgwalk + bx;
         for (int r = lane; r < n_rec; r += 64) out->rec[r] = sm.stage[r];
         if (lane == 0) out->cnt = n_rec;
@@ -613,7 +658,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
         const int c = c_next;
         c_next = (t + 64 < g.gz) ? (int)a.count[col_base + t + 64] : 0;
         const int incl = wave_incl_scan_i(((c != 0) << 16) | c, lane);
-        const int total = __shfl(incl, 63);
+        const int total = wave_bcast(incl, 63);
         const int excl = incl - (((c != 0) << 16) | c);
         const int nb_i = n_nb + (excl >> 16);
         const int off = n_entries + (excl & 0xFFFF);
@@ -656,16 +701,21 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     const int shard = ci & (PAR_ITEM_SHARDS - 1);
     int my_chunks = 0;
     bool dup = false;
+    if (role == 0 && !overflow) {
+        // an entry that repeats an earlier entry's entity: entry by entry through a scalar register (no LDS round
+        // trips: this sits on every column's chain of dependent steps)
+        const int mine = lane < n_entries ? sm.entries[min(lane, PAR_COL_ENT - 1)].entity : -1;
+        for (int e = 0; e + 1 < n_entries; e++) dup = dup || (lane > e && lane < n_entries && mine == wave_bcast(mine, e));
+    }
     if (role == 0 && !overflow && lane < n_entries) {
         const par_slot r = sm.entries[lane];
-        for (int e = 0; e < lane; e++) dup = dup || (sm.entries[e].entity == r.entity);
         const int w = min(r.px + r.ex, c0 + tw) - max((int)r.px, c0);
         const int h = min(a.H - (r.py + r.pz), rows_hi) - max(a.H - (r.py + r.ey + r.pz + r.ez), rows_lo);
         if (!dup && w > 0 && h > 0) my_chunks = (w * h + 63) >> 6;  // every visit costs whole wavefronts
     }
     const uint64_t dup_mask = __ballot(dup);
     const int chunk_incl = wave_incl_scan_i(my_chunks, lane);
-    const int pass_chunks = __shfl(chunk_incl, 63);
+    const int pass_chunks = wave_bcast(chunk_incl, 63);
     const int first_item = chunk_incl - my_chunks;
     // (a.tile_k == 0: a sparse frame, which has no launch for tile items: every column is visited entry by entry)
     const int tile_mode = (a.tile_k > 0 && pass_chunks >= tile_chunks) ? 1 : 0;
@@ -688,11 +738,11 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
         const par_frame_dyn dyn = a.dyn_ptr ? *a.dyn_ptr : a.dyn;
         for (int i = role; i < n_nb; i += ROLES) {
             const int sz = sm.nb[i].bz;
-            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, sm.chain, sm.stage, i == 0 ? a.flags : 0u);
+            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, sm.stage, i == 0 ? a.flags : 0u);
             // (a list takes an even number of records: the tile pass reads them in pairs, walk_list_lit)
             if (n_rec < 0 || n_walk + n_rec + (n_rec & 1) > kWalkPart) {
                 // more occluders on the way than the record holds: the pixels that start here walk for themselves
-                // (lane_shadow_walk in the render kernel), the column keeps its record
+                // (lane_shadow_walk in the render kernels), the column keeps its record
                 walk_failed = true;
                 if (lane == 0) {
                     sm.nb[i].woff = 0;
@@ -731,7 +781,7 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     // ---- C: the column's work items (none of them usable when the shard is full: the host sizes a shard for every
     // item of the frame, so that is belt and braces) and the record -------------------------------------------
     if (n_items > 0) {
-        item_base = __shfl(item_base, 0);
+        item_base = wave_bcast(item_base, 0);
         const bool usable = item_base + n_items <= g.item_capacity;
         // A SIMPLE column: every entry is the same entity (one distinct entry), its occupied bins are contiguous and
         // no walk from them met anything. Its items carry all the render kernel needs.
@@ -1120,7 +1170,6 @@ __device__ bool lane_shadow_walk(const par_grid_dev& g, const uint8_t* count, co
 // walk is done here.
 // ------------------------------------------------------------------------------------------------------------
 struct WaveScratch {  // per wavefront: what wave_walk needs
-    int16_t chain[3][65];
     par_slot stage[PAR_BIN_WALK];
 };
 
@@ -1374,7 +1423,7 @@ __device__ __forceinline__ void render_chunk(const par_grid_dev& g, const par_re
         for (unsigned long long pending = __ballot(need_walk); pending; pending = __ballot(need_walk)) {
             const int leader = __ffsll((long long)pending) - 1;
             const int gsy = __shfl(sy, leader), gsz = __shfl(sz, leader);
-            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, gsy, gsz, ws->chain, ws->stage);
+            const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, gsy, gsz, ws->stage);
             if (need_walk && sy == gsy && sz == gsz) {
                 if (n_rec >= 0) {
                     for (int r = 0; r < n_rec; r++) {
@@ -2382,12 +2431,15 @@ hipError_t par_launch_render(const par_grid_dev& g, const par_render_args& a, in
     int64_t wgs = item_workgroups(item_bound);
     if (a.tile_k > 0 && wgs > 1024) wgs = 1024;
     const dim3 grid((unsigned)wgs), block(PAR_WAVE_NW * 64);
+    // (experiments: PAR_EXP_RENDER_LDS bytes of unused LDS per workgroup cap the workgroups per CU, i.e. the wavefront
+    // slots the entry kernel can hold: how much of the frame time is wavefront-slot time?)
+    static const unsigned lds = [] { const char* e = std::getenv("PAR_EXP_RENDER_LDS"); return e ? (unsigned)std::atoi(e) : 0u; }();
     if (a.flags & PAR_DEBUG_FLAGS) {
-        hipLaunchKernelGGL((render_items_kernel<true, true, true>), grid, block, 0, stream, g, a);
+        hipLaunchKernelGGL((render_items_kernel<true, true, true>), grid, block, lds, stream, g, a);
     } else if (a.sprite_ids || a.out.brightness || a.out.lit || a.out.gbuf) {
-        hipLaunchKernelGGL((render_items_kernel<false, true, true>), grid, block, 0, stream, g, a);
+        hipLaunchKernelGGL((render_items_kernel<false, true, true>), grid, block, lds, stream, g, a);
     } else {  // every entity uses sprite 0 (the reference's own scenes), RGBA + palette index only
-        hipLaunchKernelGGL((render_items_kernel<false, false, false>), grid, block, 0, stream, g, a);
+        hipLaunchKernelGGL((render_items_kernel<false, false, false>), grid, block, lds, stream, g, a);
     }
     return hipGetLastError();
 }
