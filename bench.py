@@ -148,16 +148,20 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
                 parts["fill_kernel"].append(st.ms_fill)
                 parts["render_items_kernel"].append(st.ms_render)
                 parts["render_overflow_kernel"].append(st.ms_overflow)
-        launched = [[] for _ in range(4)]
+        launched = [[] for _ in range(5)]
         for i in range(13):
             st = r.render_device(ptrs, stream=stream, timed=True, flags=par.RENDER_TIMED_AS_LAUNCHED)
             if i >= 3:
-                for k in range(4):
+                for k in range(5):
                     launched[k].append(st.ms_launch[k])
         launched = [float(np.mean(v)) for v in launched]
-        clock_ghz = measured_clock_ghz(pipe, depth)
+        names = launch_names(len(aabbs))
+        if st.render_merged:  # small frames: entry items, tile items and overflow columns in one launch
+            names[2] = "render_both_kernel"
+        dom = max(range(5), key=lambda k: launched[k])  # the longest launch of the frame, as measured here
+        clock_ghz = measured_clock_ghz(pipe, depth, row=5 if dom == 3 else 3)
         counters, counters_from = load_counters(counters_key) if counters_key else ({}, None)
-        render_issue = issue_fractions(counters.get("render_items_kernel"), launched[2], clock_ghz)
+        dom_issue = issue_fractions(counters.get(names[dom]), launched[dom], clock_ghz)
         stats = r.stats()
         full = r.render(("palidx",))
         covered = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
@@ -167,11 +171,12 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
             "hbm_frac": round(5.0 * w * h / (per * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "one_frame_at_a_time_ms": round(alone, 5),
             "kernels_ms_one_at_a_time": {k: round(float(np.mean(v)), 5) for k, v in parts.items()},
-            "launches_ms_as_launched": dict(zip(launch_names(len(aabbs)), [round(v, 5) for v in launched])),
-            "render_items_kernel": dict({"avg_ms": round(launched[2], 5), "clock_ghz": clock_ghz,
-                                         "counters_from": counters_from,
-                                         "hbm_frac": round(5.0 * covered / (launched[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
-                                         if launched[2] > 0 else None}, **render_issue),
+            "launches_ms_as_launched": dict(zip(names, [round(v, 5) for v in launched])),
+            "dominant_launch": dict({"kernel": names[dom], "avg_ms": round(launched[dom], 5), "clock_ghz": clock_ghz,
+                                     "counters_from": counters_from,
+                                     # the pixel bytes the render kernels have to move, over this launch's time
+                                     "hbm_frac": round(5.0 * covered / (launched[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                     if dom in (2, 3) else None}, **dom_issue),
             "covered_pixels": covered, "pixels": w * h, "entities": int(stats.entities),
             "occupied_columns": int(stats.occupied_columns), "overflow_columns": int(stats.overflow_columns),
         }
@@ -182,7 +187,7 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
 def launch_names(n_prims):
     """The launches of a production frame in order (small scenes build the hash in one launch)."""
     build = "build_fill_kernel" if n_prims <= 16384 else "insert_fill_kernel+resolve_fill_kernel"
-    return [build, "columns_fill_kernel", "render_items_kernel", "render_overflow_kernel"]
+    return [build, "columns_fill_kernel", "render_items_kernel", "render_tiles_kernel", "render_overflow_kernel"]
 
 
 def fill_shares():
@@ -223,9 +228,10 @@ def issue_fractions(counters, ms, clock_ghz):
             "salu_frac": round(counters.get("SQ_INSTS_SALU", 0) * 4.0 / cycles, 4)}
 
 
-def measured_clock_ghz(pipe, depth):
-    """Shader clock while the render kernel runs: its workgroups' s_memtime spans over their 100 MHz wall-clock spans
-    (debug time stamps of frames rendered with flag bit 29; median over workgroups)."""
+def measured_clock_ghz(pipe, depth, row=3):
+    """Shader clock while a render kernel runs (stamp row 3: render_items_kernel, 5: render_tiles_kernel): its
+    workgroups' s_memtime spans over their 100 MHz wall-clock spans (debug time stamps of frames rendered with flag
+    bit 29; median over workgroups)."""
     import ctypes as C
     pipe.submit_many(0, depth, 1 << 29)
     pipe.synchronize()
@@ -235,7 +241,7 @@ def measured_clock_ghz(pipe, depth):
     rc = par.lib().par_debug_read_stamps(pipe.slots[0].renderer._ctx, buf.ctypes.data_as(C.c_void_p), buf.size)
     if rc != 0:
         return None
-    st = buf.reshape(rows, wgs, 8)[3]
+    st = buf.reshape(rows, wgs, 8)[row]
     live = (st[:, 0] > 0) & (st[:, 7] > st[:, 0]) & (st[:, 5] > 0)
     if not live.any():
         return None
@@ -550,10 +556,10 @@ def main():
         names = launch_names(N_PRIMS)
         for _ in range(5):
             r.render_device(ptrs, stream=stream, timed=True, flags=par.RENDER_TIMED_AS_LAUNCHED)
-        launched = [[] for _ in range(4)]
+        launched = [[] for _ in range(5)]
         for _ in range(30):
             st = r.render_device(ptrs, stream=stream, timed=True, flags=par.RENDER_TIMED_AS_LAUNCHED)
-            for i in range(4):
+            for i in range(5):
                 launched[i].append(st.ms_launch[i])
         launched = [float(np.mean(v)) for v in launched]
         ncols = int(r.stats().occupied_columns)
@@ -565,13 +571,13 @@ def main():
         bytes_frame = 2.5 * 2.0 * W * H
         bytes_render = 5.0 * hit_pixels
         fill_share = fill_shares()
-        algorithmic = [bytes_frame * fill_share[0], bytes_frame * fill_share[1], bytes_render, 0.0]
+        algorithmic = [bytes_frame * fill_share[0], bytes_frame * fill_share[1], bytes_render, 0.0, 0.0]
         clock_ghz = measured_clock_ghz(pipe, depth)
         counters, counters_from = load_counters("headline")
         traffic_json, traffic_from = load_traffic()
         launches = []
         for i, name in enumerate(names):
-            if launched[i] <= 0.0 or (i == 3 and algorithmic[i] == 0.0 and launched[i] < 1e-3):
+            if launched[i] <= 0.0:  # (no such launch in this frame)
                 continue
             e = {"kernel": name, "avg_ms": round(launched[i], 5), "algorithmic_bytes": int(algorithmic[i]),
                  "hbm_gbps": round(algorithmic[i] / (launched[i] * 1e-3) / 1e9, 1),

@@ -83,10 +83,14 @@ typedef struct par_frame_stats {
     float ms_render;         /* device time of the render kernels (render_items_kernel, and render_tiles_kernel in a
                               * dense frame) of the last timed render, else -1 */
     float ms_overflow;       /* device time of the overflow-column kernel of the last timed render, else -1 */
-    float ms_launch[4];      /* PAR_RENDER_TIMED_AS_LAUNCHED: device time of the frame's launches as a production frame
+    float ms_launch[5];      /* PAR_RENDER_TIMED_AS_LAUNCHED: device time of the frame's launches as a production frame
                               * makes them: [0] hash build (+ its share of the fill), [1] column records (+ the rest of the
-                              * fill), [2] render (work items), [3] overflow list (0 when the frame has no such launch);
+                              * fill), [2] render_items_kernel (entry work items), [3] render_tiles_kernel (whole-tile
+                              * items of a dense frame), [4] overflow list; 0 where the frame has no such launch;
                               * else -1 */
+    int32_t render_merged;   /* PAR_RENDER_TIMED_AS_LAUNCHED: 1 when the frame rendered its entry items, tile items and
+                              * overflow columns in ONE launch (render_both_kernel, small frames; its time is
+                              * ms_launch[2]), else 0 */
 } par_frame_stats;
 
 const char* par_status_string(int status);

@@ -96,7 +96,8 @@ struct par_context {
     int64_t graph_pair_bound = 0;  // (entity, bin) pairs a captured graph's launch grids can take
     int64_t graph_item_bound = 0;  // ... and render work items
 
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timed_tiles = false, timed_overflow = false, timed_both = false;  // the last timed frame launched these kernels
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     par_frame_stats stats{};
     unsigned last_flags = 0;
     std::string err;
@@ -591,11 +592,19 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     }
     if (!both) {
         PAR_HIP(par_launch_render(ctx->grid, r, item_bound, stream));
+        if (ev) PAR_HIP(hipEventRecord(ev[6], stream));
         PAR_HIP(par_launch_render_tiles(ctx->grid, r, item_bound, stream));  // (dense frames only: r.tile_k > 0)
+    } else if (ev) {
+        PAR_HIP(hipEventRecord(ev[6], stream));
     }
     if (ev) PAR_HIP(hipEventRecord(ev[4], stream));
     if (!both && may_overflow) PAR_HIP(par_launch_render_overflow(ctx->grid, r, col_bound, stream));
     if (ev) PAR_HIP(hipEventRecord(ev[2], stream));
+    if (ev) {  // which of the optional launches this frame had (par_frame_stats::ms_launch)
+        ctx->timed_tiles = !both && r.tile_k > 0;
+        ctx->timed_overflow = !both && may_overflow;
+        ctx->timed_both = both;
+    }
     return PAR_OK;
 }
 
@@ -718,7 +727,7 @@ static int par_create_impl(const par_params* params, int device, par_context** o
     if ((e = hipMalloc(&ctx->d_dyn, sizeof(par_frame_dyn))) != hipSuccess) return bail(e);
     if ((e = hipMemcpy(ctx->d_palette, p.palette, PAR_MAX_PALETTE * sizeof(par_color), hipMemcpyHostToDevice)) != hipSuccess) return bail(e);
     if ((e = hipMemset(ctx->grid.slots, 0, (size_t)ctx->volume * PAR_SLOTS * sizeof(par_slot))) != hipSuccess) return bail(e);
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 7; i++) {
         if ((e = hipEventCreate(&ctx->ev[i])) != hipSuccess) return bail(e);
     }
     if (reset_grid(ctx) != PAR_OK) {
@@ -764,7 +773,7 @@ void par_destroy(par_context* ctx) {
         if (ctx->pin_dyn[s]) (void)hipHostFree(ctx->pin_dyn[s]);
         if (ctx->ev_graph[s]) (void)hipEventDestroy(ctx->ev_graph[s]);
     }
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 7; i++) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1046,11 +1055,16 @@ static int par_render_device_timed_impl(par_context* ctx, void* stream, int row_
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_render, ctx->ev[3], ctx->ev[4]));
     PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_overflow, ctx->ev[4], ctx->ev[2]));
     for (float& v : ctx->stats.ms_launch) v = -1.f;
+    ctx->stats.render_merged = 0;
     if (flags & PAR_RENDER_TIMED_AS_LAUNCHED) {
+        ctx->stats.render_merged = ctx->timed_both ? 1 : 0;
         PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[0], ctx->ev[0], ctx->ev[5]));
         PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[1], ctx->ev[5], ctx->ev[3]));
-        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[2], ctx->ev[3], ctx->ev[4]));
-        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[3], ctx->ev[4], ctx->ev[2]));
+        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[2], ctx->ev[3], ctx->ev[6]));
+        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[3], ctx->ev[6], ctx->ev[4]));
+        PAR_HIP(hipEventElapsedTime(&ctx->stats.ms_launch[4], ctx->ev[4], ctx->ev[2]));
+        if (!ctx->timed_tiles) ctx->stats.ms_launch[3] = 0.f;  // (an empty bracket still measures the events themselves)
+        if (!ctx->timed_overflow) ctx->stats.ms_launch[4] = 0.f;
     }
     if (stats) return par_get_stats(ctx, stats);
     return check_device_error(ctx);

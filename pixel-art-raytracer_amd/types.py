@@ -55,7 +55,7 @@ class FrameStats(C.Structure):
     _fields_ = [("entities", C.c_int64), ("bin_insertions", C.c_int64), ("shadow_rays", C.c_int64),
                 ("occupied_columns", C.c_int64), ("overflow_columns", C.c_int64),
                 ("ms_bin", C.c_float), ("ms_fill", C.c_float), ("ms_render", C.c_float),
-                ("ms_overflow", C.c_float), ("ms_launch", C.c_float * 4)]
+                ("ms_overflow", C.c_float), ("ms_launch", C.c_float * 5), ("render_merged", C.c_int32)]
 
 
 def default_params(width=480, height=320, length=None, bin_size=40):

@@ -1,6 +1,7 @@
 """CPU-side checks of the product library: it loads, exports every symbol include/par_raytracer.h declares, the
 host-side scene helpers match the reference's scene, and rendering without a GPU fails loudly (no fallback)."""
 import ctypes
+import importlib
 import os
 import re
 
@@ -101,6 +102,7 @@ int main(void) {
     par_sprite_tile_floor(&s);
     printf("%d %d %d %d %zu %zu %zu %s\n", gx, gy, gz, s.depth[0], sizeof(par_pixel), sizeof(par_aabb),
            sizeof(par_sprite), par_status_string(PAR_ERR_NO_DEVICE));
+    printf("%zu %zu %zu\n", sizeof(par_params), sizeof(par_frame_stats), sizeof(par_outputs));
     return 0;
 }
 ''')
@@ -113,3 +115,8 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0
     assert out.stdout.split()[:7] == ["12", "8", "8", "19", "28", "16", "16000"]
+    # the ctypes mirrors of the structures are laid out as the header's
+    import ctypes as C
+    T = importlib.import_module("pixel-art-raytracer_amd.types")
+    assert [int(v) for v in out.stdout.splitlines()[1].split()] == [C.sizeof(T.Params), C.sizeof(T.FrameStats),
+                                                                   C.sizeof(T.Outputs)]
