@@ -317,9 +317,12 @@ def main():
         if args.assemble == "blocks":
             gather = sharding.FrameGather(H, W * 4, torch.uint8, dev, world, rank, bin_size=params.bin_size)
         elif args.assemble == "tiles":
-            tile_gathers = [sharding.TileGather(params, aabbs, dev, world, rank) for _ in range(depth)]
+            # (in place: rank 0 renders its block straight into its rows of the slot's assembled frame)
+            tile_gathers = [sharding.TileGather(params, aabbs, dev, world, rank, in_place=True) for _ in range(depth)]
+    in_place = bool(tile_gathers) and rank == 0 and has_rows
     pipe = pipeline.FramePipeline(params, aabbs, sprite, light, depth=depth, device=local_rank,
-                                  rows=(r0, r1) if has_rows else (0, 1), planes=("fb", "palidx"), rows_alloc=rows_alloc)
+                                  rows=(r0, r1) if has_rows else (0, 1), planes=("fb", "palidx"), rows_alloc=rows_alloc,
+                                  fb_targets=[tg.root_block() for tg in tile_gathers] if in_place else None)
     r = pipe.slots[0].renderer
     fb = [s_.buffers["fb"] for s_ in pipe.slots]
     pal = [s_.buffers["palidx"] for s_ in pipe.slots]

@@ -220,6 +220,14 @@ int par_tiles_unpack(const par_params* params, void* stream, const int32_t* d_ti
                      par_color* frame);
 /* The background (Color{background} * ambient, alt:281, 735) for n_rows whole rows starting at `rows`. */
 int par_background_fill(const par_params* params, void* stream, par_color* rows, int n_rows);
+/* Both of the above in one pass, for the rows the assembling rank did not render itself: rows [row_begin, row_end) of
+ * the frame (`frame` addresses row 0) are written exactly once -- a packed tile's pixels where `d_map` (device array
+ * of grid-x * grid-y entries: tile column + tile row * grid-x -> slot in `packed`, -1 = background) names one, the
+ * background elsewhere. par_scene_tile_map makes the host copy of the map from the tile list (capacity >= grid-x *
+ * grid-y entries). */
+int par_tiles_assemble(const par_params* params, void* stream, const int32_t* d_map, const par_color* packed,
+                       par_color* frame, int row_begin, int row_end);
+int par_scene_tile_map(const par_params* params, const int32_t* tiles, int n, int32_t* map, int capacity);
 
 /* Debug overlay of alt:763-772 (Bresenham line from the picked pixel to the light) drawn into a host frame. */
 void par_debug_line(const par_params* params, const par_pixel* pick, int mouse_x, const par_light* light,

@@ -39,7 +39,7 @@ ABI_SYMBOLS = (
     "par_graph_capture", "par_graph_stage", "par_graph_launch", "par_pick", "par_get_stats", "par_read_grid",
     "par_sprite_tile_floor", "par_scene_graybox", "par_scene_synthetic", "par_debug_line", "par_debug_units",
     "par_render_device_slots", "par_row_block", "par_scene_tiles", "par_tiles_pack", "par_tiles_unpack",
-    "par_background_fill",
+    "par_background_fill", "par_tiles_assemble", "par_scene_tile_map",
 )
 
 
@@ -120,6 +120,8 @@ def lib():
         L.par_tiles_pack.argtypes = [vp, vp, vp, i32, vp, i32, i32, vp]
         L.par_tiles_unpack.argtypes = [vp, vp, vp, i32, vp, vp]
         L.par_background_fill.argtypes = [vp, vp, vp, i32]
+        L.par_tiles_assemble.argtypes = [vp, vp, vp, vp, vp, i32, i32]
+        L.par_scene_tile_map.argtypes = [vp, vp, i32, vp, i32]
         L.par_debug_read_stamps.argtypes = [vp, vp, C.c_size_t]
         L.par_debug_line.restype = None
         L.par_debug_line.argtypes = [vp, vp, i32, vp, vp]
@@ -338,6 +340,26 @@ def scene_tiles(params, aabbs):
     if n < 0:
         raise ParError(-n, "par_scene_tiles")
     return tiles[:n].copy()
+
+
+def scene_tile_map(params, tiles):
+    """tile column + tile row * grid-x -> index of the tile in `tiles` (its slot in a packed buffer), -1 elsewhere."""
+    t = np.ascontiguousarray(tiles, dtype=np.int32)
+    gx, gy, _ = params.grid_dims()
+    m = np.empty(gx * gy, dtype=np.int32)
+    rc = lib().par_scene_tile_map(C.byref(params), ptr(t), len(t), ptr(m), len(m))
+    if rc != PAR_OK:
+        raise ParError(rc, "par_scene_tile_map")
+    return m
+
+
+def tiles_assemble(params, d_map, packed, frame, rows, stream=0):
+    """Device pointers (ints): rows [rows[0], rows[1]) of the frame at `frame` (row 0) from the packed tiles the map
+    names and the background elsewhere, in one pass (asynchronous)."""
+    rc = lib().par_tiles_assemble(C.byref(params), C.c_void_p(stream), C.c_void_p(d_map), C.c_void_p(packed),
+                                  C.c_void_p(frame), rows[0], rows[1])
+    if rc != PAR_OK:
+        raise ParError(rc, "par_tiles_assemble")
 
 
 def tiles_pack(params, d_tiles, n, fb_block, rows, packed, stream=0):

@@ -1342,6 +1342,18 @@ int par_background_fill(const par_params* p, void* stream, par_color* rows, int 
                                                (hipStream_t)stream);
     return e == hipSuccess ? PAR_OK : PAR_ERR_HIP;
 }
+int par_tiles_assemble(const par_params* p, void* stream, const int32_t* d_map, const par_color* packed, par_color* frame,
+                       int row_begin, int row_end) {
+    int gx, gy, gz;
+    if (!p || par_grid_dims(p, &gx, &gy, &gz) != PAR_OK || !d_map || !frame || !packed || row_begin < 0 ||
+        row_end > p->height || row_begin > row_end || !(p->ambient >= 0.f && p->ambient <= 1.f)) {
+        return PAR_ERR_INVALID_ARG;
+    }
+    const uint32_t ch = (uint32_t)(uint8_t)((float)p->background * p->ambient);  // Color{127,127,127,0} * ambient
+    const hipError_t e = par_launch_tiles_assemble(d_map, gx, p->width, p->bin_size, row_begin, row_end, packed, frame,
+                                                   ch | (ch << 8) | (ch << 16), (hipStream_t)stream);
+    return e == hipSuccess ? PAR_OK : PAR_ERR_HIP;
+}
 
 // ---- the exported entry points of the bodies above: no exception leaves the library -----------------------
 int par_set_sprites(par_context* ctx, const par_sprite* sprites, int n_sprites) {

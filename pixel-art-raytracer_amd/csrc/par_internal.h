@@ -251,6 +251,8 @@ hipError_t par_launch_render_overflow(const par_grid_dev& g, const par_render_ar
 hipError_t par_launch_tiles_copy(bool pack, const int32_t* d_tiles, int n, int W, int H, int B, int row_begin, int row_end,
                                  const void* src, void* dst, hipStream_t stream);
 hipError_t par_launch_background(void* dst, size_t n_px, uint32_t rgba, hipStream_t stream);
+hipError_t par_launch_tiles_assemble(const int32_t* d_map, int gx, int W, int B, int row_begin, int row_end,
+                                     const void* packed, void* frame, uint32_t rgba, hipStream_t stream);
 
 // Test hook: the device functions slab_hit / color_scale / normalize_l1_and_inverse on caller-supplied vectors (device pointers).
 hipError_t par_launch_units(int kind, const void* in_a, const void* in_b, int n, void* out, hipStream_t stream);

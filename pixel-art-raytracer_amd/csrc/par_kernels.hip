@@ -2538,6 +2538,43 @@ __global__ __launch_bounds__(256) void background_rows_kernel(uint32_t* dst, siz
     }
     if (blockIdx.x == 0 && threadIdx.x < (n_px & 3)) dst[(n4 << 2) + threadIdx.x] = rgba;
 }
+
+// Rows [row_begin, row_end) of an assembled frame in ONE pass over them: where `map` (tile column + tile row * gx ->
+// slot, or -1) names a packed tile, the tile's pixels, else the background. The frame is written exactly once (the
+// separate background fill + unpack wrote the covered tiles twice and took two launches). VEC = pixels per thread
+// and step: 4 (16-byte pieces; W and B are multiples of 4, so a piece lies within one tile) or 1.
+template <int VEC>
+__global__ __launch_bounds__(256) void tiles_assemble_kernel(const int32_t* __restrict__ map, int gx, int W, int B,
+                                                             int row_begin, int row_end,
+                                                             const uint32_t* __restrict__ packed,
+                                                             uint32_t* __restrict__ frame, uint32_t rgba,
+                                                             uint32_t magic_b) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int x = q * VEC;
+    if (x >= W) return;
+    // (divisions by the bin size through its reciprocal, as div_bin: an integer division per piece and row would cost
+    // this streaming kernel as many issue cycles as its stores take)
+    const int bx = (int)__umulhi((uint32_t)x, magic_b), xin = x - bx * B;
+#pragma unroll 4
+    for (int y = row_begin + (int)blockIdx.y; y < row_end; y += (int)gridDim.y) {
+        const int by = (int)__umulhi((uint32_t)y, magic_b);
+        const int slot = map[(size_t)by * gx + bx];
+        const size_t at = (size_t)y * (size_t)W + (size_t)x;
+        if (VEC == 4) {
+            u32x4 v = {rgba, rgba, rgba, rgba};
+            if (slot >= 0) {
+                v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(packed + (size_t)slot * (size_t)(B * B) +
+                                                                              (size_t)((y - by * B) * B + xin)));
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(frame + at));
+        } else {
+            uint32_t v = rgba;
+            if (slot >= 0) v = packed[(size_t)slot * (size_t)(B * B) + (size_t)((y - by * B) * B + xin)];
+            frame[at] = v;
+        }
+    }
+}
 }  // namespace
 
 hipError_t par_launch_tiles_copy(bool pack, const int32_t* d_tiles, int n, int W, int H, int B, int row_begin, int row_end,
@@ -2560,6 +2597,27 @@ hipError_t par_launch_background(void* dst, size_t n_px, uint32_t rgba, hipStrea
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(background_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<uint32_t*>(dst), n_px,
                        rgba);
+    return hipGetLastError();
+}
+
+hipError_t par_launch_tiles_assemble(const int32_t* d_map, int gx, int W, int B, int row_begin, int row_end,
+                                     const void* packed, void* frame, uint32_t rgba, hipStream_t stream) {
+    const int rows = row_end - row_begin;
+    if (rows <= 0 || W <= 0) return hipSuccess;
+    const bool wide = (W % 4 == 0) && (B % 4 == 0) && ((uintptr_t)frame % 16 == 0) && ((uintptr_t)packed % 16 == 0);
+    const uint32_t magic_b = (uint32_t)((1ull << 32) / (uint64_t)B + 1ull);  // (exact while coordinate * B < 2^32)
+    const int per_row = wide ? W / 4 : W;
+    const unsigned bx = (unsigned)((per_row + 255) / 256);
+    // each workgroup streams a few rows: about 2 048 workgroups write at the rate HBM takes
+    static const int target = [] { const char* e = std::getenv("PAR_TUNE_ASSEMBLE_WGS"); return e ? std::atoi(e) : 2048; }();
+    unsigned by = (unsigned)std::max(1, std::min(std::min(rows, 65535), (int)((unsigned)std::max(target, 1) / bx)));
+    if (wide) {
+        hipLaunchKernelGGL(tiles_assemble_kernel<4>, dim3(bx, by), dim3(256), 0, stream, d_map, gx, W, B, row_begin, row_end,
+                           static_cast<const uint32_t*>(packed), static_cast<uint32_t*>(frame), rgba, magic_b);
+    } else {
+        hipLaunchKernelGGL(tiles_assemble_kernel<1>, dim3(bx, by), dim3(256), 0, stream, d_map, gx, W, B, row_begin, row_end,
+                           static_cast<const uint32_t*>(packed), static_cast<uint32_t*>(frame), rgba, magic_b);
+    }
     return hipGetLastError();
 }
 

@@ -220,6 +220,19 @@ int par_scene_tiles(const par_params* p, const par_aabb* aabbs, int n, int32_t* 
     return count;
 }
 
+int par_scene_tile_map(const par_params* p, const int32_t* tiles, int n, int32_t* map, int capacity) {
+    int gx, gy, gz;
+    if (!p || n < 0 || (n > 0 && !tiles) || !map || par_grid_dims(p, &gx, &gy, &gz) != PAR_OK) return PAR_ERR_INVALID_ARG;
+    if ((long long)capacity < (long long)gx * gy) return PAR_ERR_INVALID_ARG;
+    for (long long i = 0; i < (long long)gx * gy; i++) map[i] = -1;
+    for (int i = 0; i < n; i++) {
+        const int bx = tiles[i] & 0xFFFF, by = tiles[i] >> 16;
+        if (bx >= gx || by < 0 || by >= gy) return PAR_ERR_INVALID_ARG;
+        map[(size_t)by * gx + bx] = i;
+    }
+    return PAR_OK;
+}
+
 void par_row_block(int rank, int ranks, int height, int bin_size, int* begin, int* end) {
     if (ranks < 1) ranks = 1;
     if (bin_size < 1) bin_size = 1;

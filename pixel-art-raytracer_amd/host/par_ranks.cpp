@@ -5,13 +5,16 @@
 // reference's language) would run.
 //
 //   par_ranks --ranks N --rank R --id-file PATH [--device D] [--size S] [--prims P] [--frames F] [--inflight K]
-//             [--gather tiles|blocks|none] [--check]
+//             [--gather tiles|tiles-copy|blocks|none] [--check]
 //
 // --gather tiles (default): only the screen tiles that can show a primitive travel (par_scene_tiles: every rank holds
 //   the whole scene, hence the same list; sorted by bin row, so a rank's block is one contiguous run of it). Every rank
-//   packs its run (par_tiles_pack) and sends it to rank 0 (ncclSend / ncclRecv in one group: the runs differ in
-//   length); rank 0 writes the background itself (par_background_fill) and unpacks every run, its own included
-//   (par_tiles_unpack). At 4096^2 / 1024 primitives about 3 000 of 10 609 tiles: 19 MB instead of 64 MiB per frame.
+//   but rank 0 packs its run (par_tiles_pack) and sends it to rank 0 (ncclSend / ncclRecv in one group: the runs
+//   differ in length); rank 0 renders its own block straight into its rows of the assembled frame and writes every
+//   other row exactly once, a received tile or the background (par_tiles_assemble). At 4096^2 / 1024 primitives
+//   2 536 of 10 609 tiles: 16 MB instead of 64 MiB per frame, of which rank 0's own share does not travel.
+// --gather tiles-copy: the same exchange with rank 0 treating its own block like everyone's (pack, then background
+//   fill and unpack of every run: par_background_fill, par_tiles_unpack) -- what a one-rank run can exercise.
 // --gather blocks: ONE ncclGather of the row blocks per frame, padded to the largest block (block q of frame slot k
 //   lies at q * max_block_bytes in slot k's gathered buffer on rank 0).
 // --gather none: the frame stays sharded (what a consumer that reads the blocks where they are rendered sees): the
@@ -19,8 +22,8 @@
 // Start one process per rank with the same --id-file (rank 0 writes the RCCL unique ids there, the others wait for
 // them); --device defaults to R modulo the visible devices.
 // --check: rank 0 compares the assembled frame with its own render of the whole frame (none: every rank its block).
-// With --ranks 1 the exchange is local (tiles: pack, background, unpack on the one GPU; blocks: RCCL's copy of the
-// only block): that is what a one-GPU box can run of this path.
+// With --ranks 1 the exchange is local (tiles-copy: pack, background, unpack on the one GPU; tiles: the frame is
+// rendered in place; blocks: RCCL's copy of the only block): that is what a one-GPU box can run of this path.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -99,11 +102,13 @@ int main(int argc, char** argv) {
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     g_rank = rank;
-    const bool g_tiles = gather == "tiles", g_blocks = gather == "blocks", g_none = gather == "none";
+    const bool g_copy = gather == "tiles-copy";  // (the root packs and unpacks its own tiles too; tests with one rank)
+    const bool g_tiles = gather == "tiles" || g_copy, g_blocks = gather == "blocks", g_none = gather == "none";
+    const bool in_place = g_tiles && !g_copy;
     if (ranks < 1 || rank < 0 || rank >= ranks || inflight < 1 || inflight > 16 || frames < 1 || id_file.empty() ||
         !(g_tiles || g_blocks || g_none)) {
         std::fprintf(stderr, "usage: par_ranks --ranks N --rank R --id-file PATH [--device D] [--size S] [--prims P] "
-                             "[--frames F] [--inflight K] [--gather tiles|blocks|none] [--check]\n");
+                             "[--frames F] [--inflight K] [--gather tiles|tiles-copy|blocks|none] [--check]\n");
         return 2;
     }
     int ndev = 0;
@@ -138,6 +143,7 @@ int main(int argc, char** argv) {
     std::vector<int32_t> tiles;
     std::vector<int> t_first((size_t)ranks, 0), t_count((size_t)ranks, 0);
     int32_t* d_tiles = nullptr;
+    int32_t* d_map = nullptr;
     const size_t slot_px = (size_t)B * B;
     if (g_tiles) {
         int gx = 0, gy = 0, gz = 0;
@@ -158,6 +164,13 @@ int main(int argc, char** argv) {
         }
         HIP_OK(hipMalloc(&d_tiles, std::max<size_t>(tiles.size(), 1) * sizeof(int32_t)));
         if (n) HIP_OK(hipMemcpy(d_tiles, tiles.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (rank == 0 && in_place) {  // tile -> slot of the inbox, for the one-pass assembly of the other ranks' rows
+            std::vector<int32_t> map((size_t)gx * gy);
+            const int rc = par_scene_tile_map(&params, tiles.data(), n, map.data(), (int)map.size());
+            if (rc != PAR_OK) { std::fprintf(stderr, "par_scene_tile_map: %s\n", par_status_string(rc)); return 1; }
+            HIP_OK(hipMalloc(&d_map, map.size() * sizeof(int32_t)));
+            HIP_OK(hipMemcpy(d_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     }
 
     // one communicator per frame slot (each slot's gathers run on the slot's own stream)
@@ -206,6 +219,7 @@ int main(int argc, char** argv) {
             }
         }
         s.out.fb = s.block;
+        if (rank == 0 && in_place) s.out.fb = s.frame + (size_t)my0 * W;  // rank 0 renders into its rows of the frame
         s.out.palidx = s.pal;
     }
 
@@ -219,7 +233,7 @@ int main(int argc, char** argv) {
             NCCL_OK(ncclGather(s.block, s.gathered, block_px * sizeof(par_color), ncclUint8, 0, s.comm, s.stream));
         } else if (g_tiles) {  // its tiles to rank 0, which writes the background itself
             const int mine = t_count[(size_t)rank];
-            if (mine) {
+            if (mine && !(rank == 0 && in_place)) {
                 PAR_OK_(s.ctx, par_tiles_pack(&params, s.stream, d_tiles + t_first[(size_t)rank], mine, s.block, my0, my1,
                                               rank == 0 ? s.inbox + (size_t)t_first[0] * slot_px : s.packed));
             }
@@ -237,7 +251,10 @@ int main(int argc, char** argv) {
                 }
                 NCCL_OK(ncclGroupEnd());
             }
-            if (rank == 0) {
+            if (rank == 0 && in_place) {  // every row rank 0 did not render, written once: tile or background
+                if (my0 > 0) PAR_OK_(s.ctx, par_tiles_assemble(&params, s.stream, d_map, s.inbox, s.frame, 0, my0));
+                if (my1 < H) PAR_OK_(s.ctx, par_tiles_assemble(&params, s.stream, d_map, s.inbox, s.frame, my1, H));
+            } else if (rank == 0) {
                 PAR_OK_(s.ctx, par_background_fill(&params, s.stream, s.frame, H));
                 PAR_OK_(s.ctx, par_tiles_unpack(&params, s.stream, d_tiles, (int)tiles.size(), s.inbox, s.frame));
             }
@@ -310,5 +327,6 @@ int main(int argc, char** argv) {
     }
     (void)hipFree(d_flag);
     if (d_tiles) (void)hipFree(d_tiles);
+    if (d_map) (void)hipFree(d_map);
     return bad ? 1 : 0;
 }

@@ -35,17 +35,23 @@ class FramePipeline:
     stream kept so far (a few dozen small probe frames each)."""
 
     def __init__(self, params, aabbs, sprites, light, depth=4, device=0, rows=None, planes=("fb", "palidx"),
-                 rows_alloc=None, sprite_ids=None, calibrate=True):
+                 rows_alloc=None, sprite_ids=None, calibrate=True, fb_targets=None):
+        """`fb_targets`: one caller-owned uint8 tensor per slot to render the RGBA block into (e.g. the slot's rows of
+        an assembled frame) instead of a buffer of the pipeline's own."""
         dev = torch.device("cuda", device)
         r0, r1 = rows or (0, params.height)
         n_rows = rows_alloc or (r1 - r0)
         self.params = params
         self.slots = []
-        for _ in range(depth):
+        for k_slot in range(depth):
             r = Renderer(params, device)
             r.set_scene(aabbs, sprites, light, sprite_ids)
             bufs = {k: torch.zeros(n_rows * params.width * plane_bytes(k), dtype=torch.uint8, device=dev)
-                    for k in planes}
+                    for k in planes if not (k == "fb" and fb_targets)}
+            if fb_targets and "fb" in planes:
+                if fb_targets[k_slot].numel() < (r1 - r0) * params.width * plane_bytes("fb"):
+                    raise ValueError("fb target smaller than the row block")
+                bufs["fb"] = fb_targets[k_slot]
             self.slots.append(FrameSlot(r, None, bufs, (r0, r1)))
         candidates = [torch.cuda.Stream(device=dev) for _ in range(depth if depth < 2 or not calibrate else 3 * depth)]
         chosen = self._pick_streams(candidates, depth) if calibrate and depth > 1 else candidates[:depth]

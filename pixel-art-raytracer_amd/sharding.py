@@ -109,9 +109,14 @@ class TileGather:
     list is sorted by bin row and row blocks are cut at bin rows: a rank's tiles are one contiguous run); nothing but
     pixels is exchanged. Per frame: every rank packs its run out of its block (par_tiles_pack), sends it to `dst`
     (point to point: the runs differ in length); `dst` fills the frame with the background and unpacks all runs, its
-    own included (par_tiles_unpack). The scene must not change between the ranks' calls of one frame."""
+    own included (par_tiles_unpack). The scene must not change between the ranks' calls of one frame.
 
-    def __init__(self, params, aabbs, device, world=None, rank=None, dst=0, group=None):
+    `in_place`: the root renders its own block straight into its rows of the assembled frame (`root_block()`), packs
+    and copies nothing of its own, and writes every OTHER row exactly once, tile or background, in one pass
+    (par_tiles_assemble) -- the root is the rank with the most to do, and this takes a launch and a third of the
+    bytes off it."""
+
+    def __init__(self, params, aabbs, device, world=None, rank=None, dst=0, group=None, in_place=False):
         from . import scene_tiles
         self.group = group
         self.world = dist.get_world_size(group) if world is None else world
@@ -120,8 +125,10 @@ class TileGather:
         self.params = params
         self.device = torch.device(device)
         self.slot_bytes = params.bin_size * params.bin_size * 4
+        self.in_place = in_place
         self.frame = None
         self.inbox = None
+        self.d_map = None
         self.set_scene(aabbs)
         if self.rank == dst:
             self.frame = torch.zeros(params.height * params.width * 4, dtype=torch.uint8, device=self.device)
@@ -142,10 +149,23 @@ class TileGather:
         if self.rank == self.dst:
             # every rank's run, in list order, in one buffer (the root's own run is copied in locally)
             self.inbox = torch.zeros(max(len(self.tiles), 1) * self.slot_bytes, dtype=torch.uint8, device=self.device)
+            if self.in_place:
+                from . import scene_tile_map
+                own = scene_tile_map(p, self.tiles)
+                f, e = self.first[self.rank], self.end[self.rank]
+                own[(own >= f) & (own < e)] = -1  # (the root's own tiles are already in place)
+                self.tile_map = own
+                self.d_map = torch.from_numpy(own).to(self.device)
 
     @property
     def max_rows(self):
         return max(e - b for b, e in self.blocks)
+
+    def root_block(self):
+        """in_place, root: its own rows of the assembled frame -- what it renders its block into."""
+        b, e = self.blocks[self.rank]
+        w4 = self.params.width * 4
+        return self.frame[b * w4:e * w4]
 
     def bytes_sent(self, rank=None):
         r = self.rank if rank is None else rank
@@ -163,7 +183,7 @@ class TileGather:
     def pack(self, block, packed, stream=0):
         """This rank's run of tiles out of its rendered block (asynchronous on `stream` for device tensors)."""
         n, first = self.counts[self.rank], self.first[self.rank]
-        if n == 0:
+        if n == 0 or (self.in_place and self.rank == self.dst):
             return
         rows = self.blocks[self.rank]
         if block.is_cuda:
@@ -181,7 +201,7 @@ class TileGather:
         ops = []
         if self.rank == self.dst:
             f, n = self.first[self.rank], self.counts[self.rank]
-            if n:
+            if n and not self.in_place:
                 self.inbox[f * sb:(f + n) * sb].copy_(packed[:n * sb])
             for r in range(self.world):
                 if r != self.dst and self.counts[r]:
@@ -200,7 +220,7 @@ class TileGather:
         torch.cuda.current_stream().synchronize()
         if self.rank == self.dst:
             f, n = self.first[self.rank], self.counts[self.rank]
-            if n:
+            if n and not self.in_place:
                 self.inbox[f * sb:(f + n) * sb].copy_(packed[:n * sb])
             for r in range(self.world):
                 if r != self.dst and self.counts[r]:
@@ -217,6 +237,26 @@ class TileGather:
         if self.rank != self.dst:
             return
         p = self.params
+        if self.in_place:
+            b, e = self.blocks[self.rank]
+            others = [(0, b), (e, p.height)]
+            if self.frame.is_cuda:
+                from . import tiles_assemble
+                for rows in others:
+                    if rows[1] > rows[0]:
+                        tiles_assemble(p, self.d_map.data_ptr(), self.inbox.data_ptr(), self.frame.data_ptr(), rows, stream)
+            else:
+                ch = int(float(p.background) * float(p.ambient))
+                w4 = p.width * 4
+                for lo, hi in others:
+                    f = self.frame[lo * w4:hi * w4].view(-1, 4)
+                    f[:, 0:3] = ch
+                    f[:, 3] = 0
+                for r in range(self.world):
+                    if r != self.rank and self.counts[r]:
+                        _tiles_copy_cpu(p, self.tiles[self.first[r]:self.end[r]], self.frame, (0, p.height),
+                                        self.inbox[self.first[r] * self.slot_bytes:], pack=False)
+            return
         if self.frame.is_cuda:
             from . import background_fill, tiles_unpack
             background_fill(p, self.frame.data_ptr(), p.height, stream)

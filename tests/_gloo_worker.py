@@ -33,10 +33,14 @@ def main():
     gbuf, _ = o.primary(params, grid, sprite, rows=(r0, r1))
     fb, _, _ = o.shade(params, grid, gbuf, light, rows=(r0, r1))
     mine = torch.from_numpy(fb[r0 * width:r1 * width].view(np.uint8).copy())
-    if mode == "tiles":
-        # only the tiles that can show a primitive travel; the root writes the background itself (TileGather)
-        g = sharding.TileGather(params, aabbs, "cpu", world, rank)
-        block = g.block_buffer()
+    if mode in ("tiles", "tiles_in_place"):
+        # only the tiles that can show a primitive travel; the root writes the background itself (TileGather);
+        # in place: the root's own block is produced straight into its rows of the assembled frame
+        g = sharding.TileGather(params, aabbs, "cpu", world, rank, in_place=(mode == "tiles_in_place"))
+        if g.in_place and rank == 0:
+            block = g.root_block()
+        else:
+            block = g.block_buffer()
         block[:mine.numel()] = mine
         packed = g.packed_buffer()
         g.pack(block, packed)

@@ -516,7 +516,9 @@ def test_eight_row_blocks_and_their_tiles_assemble_the_headline_frame(par, oracl
     """The partition an 8-GPU run of the headline uses, on one GPU: the eight blocks par_row_block(r, 8, 4096, 40)
     rendered one by one (a) concatenate to the whole-frame render, which equals the oracle; (b) packed into the tiles
     that can show a primitive (par_scene_tiles / par_tiles_pack) and assembled on a background-filled frame
-    (par_background_fill / par_tiles_unpack) give the same frame -- what rank 0 of the sharded run does."""
+    (par_background_fill / par_tiles_unpack) give the same frame; (c) with rank 0's block rendered straight into its
+    rows of the frame and every other row written once from the tile map (par_scene_tile_map / par_tiles_assemble):
+    the same frame again -- what rank 0 of the sharded run does."""
     import importlib
     import torch
     sharding = importlib.import_module("pixel-art-raytracer_amd.sharding")
@@ -548,11 +550,57 @@ def test_eight_row_blocks_and_their_tiles_assemble_the_headline_frame(par, oracl
         par.background_fill(params, frame.data_ptr(), h)
         par.tiles_unpack(params, d_tiles.data_ptr(), len(tiles), inbox.data_ptr(), frame.data_ptr())
         torch.cuda.synchronize()
+        # (c) in place, for the first, a middle and the last block as the assembling rank's own
+        d_map = torch.from_numpy(par.scene_tile_map(params, tiles)).to(dev)
+        in_place = []
+        for root in (0, 3, 7):
+            f2 = torch.full((h * w * 4,), 9, dtype=torch.uint8, device=dev)
+            b, e = blocks[root]
+            r.render_device({"fb": f2.data_ptr() + b * w * 4}, rows=(b, e))
+            par.tiles_assemble(params, d_map.data_ptr(), inbox.data_ptr(), f2.data_ptr(), (0, b))
+            par.tiles_assemble(params, d_map.data_ptr(), inbox.data_ptr(), f2.data_ptr(), (e, h))
+            torch.cuda.synchronize()
+            in_place.append(f2.cpu().numpy())
     whole_fb = whole["fb"].view(np.uint8)
     assert np.array_equal(np.concatenate(parts), whole_fb)
     assert np.array_equal(frame.cpu().numpy(), whole_fb)
+    for f2 in in_place:
+        assert np.array_equal(f2, whole_fb)
     exp = oracle.render(params, aabbs, sprite, light, nthreads=os.cpu_count() or 8, planes=("fb", "palidx"))
     assert whole["fb"].tobytes() == exp["fb"].tobytes() and whole["palidx"].tobytes() == exp["palidx"].tobytes()
+
+
+@pytest.mark.parametrize("w,h,b", [(333, 170, 16), (250, 200, 10), (480, 320, 40)])
+def test_tiles_assemble_on_views_of_any_width(par, sprite, T, w, h, b):
+    """par_tiles_assemble where the 16-byte path does not apply (width or bin size not a multiple of 4) and where it
+    does: three ranks' blocks packed, the root's (rank 1) rendered in place, the other rows assembled in one pass."""
+    import importlib
+    import torch
+    sharding = importlib.import_module("pixel-art-raytracer_amd.sharding")
+    params = T.default_params(w, h, 120, b)
+    aabbs, light = par.scene_synthetic(90, w, h, 120, 31)
+    dev = torch.device("cuda", 0)
+    gathers = [sharding.TileGather(params, aabbs, dev, world=3, rank=q, dst=1, in_place=True) for q in range(3)]
+    root = gathers[1]
+    slot = root.slot_bytes
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        whole = r.render(("fb",))["fb"].view(np.uint8)
+        for q, g in enumerate(gathers):
+            rows = g.blocks[q]
+            if rows[1] <= rows[0]:
+                continue
+            if q == 1:
+                r.render_device({"fb": root.root_block().data_ptr()}, rows=rows)
+                continue
+            blk, packed = g.block_buffer(), g.packed_buffer()
+            r.render_device({"fb": blk.data_ptr()}, rows=rows)
+            g.pack(blk, packed)
+            n = g.counts[q]
+            root.inbox[g.first[q] * slot:(g.first[q] + n) * slot] = packed[:n * slot]  # (what the send would do)
+        root.assemble()
+        torch.cuda.synchronize()
+    assert np.array_equal(root.frame.cpu().numpy(), whole)
 
 
 def test_host_demo_gif(par, oracle, T, tmp_path):
@@ -799,11 +847,12 @@ def test_cpp_pipeline_host(par):
         assert line["host"] == "C++" and line["frames_per_s"] > 0
 
 
-@pytest.mark.parametrize("gather", ["tiles", "blocks", "none"])
+@pytest.mark.parametrize("gather", ["tiles", "tiles-copy", "blocks", "none"])
 def test_cpp_ranks_host_gathers_over_rccl(par, tmp_path, gather):
     """The sharded-frame loop in host C++ (par_ranks): one process per GPU, row blocks cut at bin rows, the frame's
     exchange enqueued behind the render on the frame's stream: the tiles that can show a primitive to rank 0, which
-    writes the background itself (tiles), ONE ncclGather of the blocks (blocks), or nothing (none). A one-GPU box can
+    writes the background itself (tiles: rank 0's own block rendered in place in the assembled frame; tiles-copy: its
+    block packed and unpacked like everyone's), ONE ncclGather of the blocks (blocks), or nothing (none). A one-GPU box can
     run it with one rank, which still executes the whole per-frame path: communicator set-up from the id file, render
     into the block, pack / background / unpack (or RCCL's gather of the only block), assembled frame equal to the
     whole-frame render (--check)."""
@@ -819,7 +868,7 @@ def test_cpp_ranks_host_gathers_over_rccl(par, tmp_path, gather):
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert line["host"] == "C++ ranks" and line["ranks"] == 1 and line["gather"] == gather
     assert line["bytes_to_rank0_per_frame"] == 0  # (one rank: nothing travels)
-    if gather == "tiles":
+    if gather in ("tiles", "tiles-copy"):
         assert 0 < line["tiles"] < 26 * 26
 
 

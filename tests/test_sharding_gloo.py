@@ -38,10 +38,12 @@ def test_row_blocks_partition():
 
 
 @pytest.mark.parametrize("world,height,mode", [(2, 160, "blocks"), (3, 200, "blocks"), (2, 320, "blocks"),
-                                               (2, 320, "tiles"), (3, 200, "tiles")])
+                                               (2, 320, "tiles"), (3, 200, "tiles"), (2, 320, "tiles_in_place"),
+                                               (3, 200, "tiles_in_place")])
 def test_gather_assembles_the_frame(tmp_path, world, height, mode):
     """mode "blocks": whole row blocks gathered (FrameGather); "tiles": only the tiles that can show a primitive
-    travel and the root writes the background itself (TileGather)."""
+    travel and the root writes the background itself (TileGather); "tiles_in_place": the same with the root's own
+    block produced straight into the assembled frame."""
     out = tmp_path / "result.txt"
     env = dict(os.environ, OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
