@@ -93,7 +93,7 @@ struct par_colrec {
 static_assert(sizeof(par_colrec_nb) == 8 && sizeof(par_colrec) % 16 == 0, "column record layout");
 static_assert(PAR_COL_ENT <= 64, "one duplicate bit per entry, one entry per lane");
 static_assert((PAR_COL_NB & (PAR_COL_NB - 1)) == 0 && PAR_COL_NB <= 64, "one occupied bin per lane");
-static_assert(PAR_COL_WALK % 2 == 0, "two wavefronts may share a column's walks, each with half of the walk area");
+static_assert(PAR_COL_WALK % 2 == 0, "a walk list takes an even number of records (the tile pass reads them in pairs)");
 
 // The shadow walk of BACKGROUND pixels (every ray traced as the reference does): an uncovered pixel has world
 // position (x, 0, 0) (alt:281, 707-709), so its ray starts in bin (x / B, H / B, 0) whatever its row -- one walk per

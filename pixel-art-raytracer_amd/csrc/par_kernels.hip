@@ -625,9 +625,17 @@ __device__ __forceinline__ void tile_candidate_masks(const par_render_args& a, c
 // occupied bins r, r + roles, ... and the r-th part of the record's walk area); role 0 does everything else. The
 // others repeat the scan of the column's counts (they need the list of occupied bins) and leave at once when the
 // column has no walk for them.
+// What the wavefronts of one column share (ROLES > 1: the workgroup is one column's team).
+struct ColTeam {
+    int32_t found[8];   // per role: did any of its walks meet an occupied bin (or fail to fit)?
+    int32_t walk_used;  // records of the column's walk area handed out so far
+};
+constexpr int PAR_COL_MAX_ROLES = 8;
+
 template <int ROLES>
 __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_render_args& a, ColWave& sm,
-                                             int32_t* others_found, int ci, int role, int n_cols_bound) {
+                                             ColTeam* team_sh, int ci, int role, int n_cols_bound) {
+    static_assert(ROLES >= 1 && ROLES <= PAR_COL_MAX_ROLES, "ColTeam::found has one word per role");
     const int lane = (int)threadIdx.x & 63;
     if (ci >= n_cols_bound) {
         const int bx = ci - n_cols_bound;
@@ -685,7 +693,10 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     }
     wave_lds_fence();
     if (role == 0) stamp(g, a.flags, 2, 2);
-    if (role != 0 && (overflow || n_nb <= role)) return;  // no walk for this wavefront
+    // The column's wavefronts work as a team exactly when it has walks to share (every one of them has scanned the same
+    // counts and knows): then all of them stay until the barrier behind the walks, with or without a walk of their own.
+    const bool team = ROLES > 1 && !overflow && n_nb >= 2;
+    if (role != 0 && !team) return;  // no walk for this wavefront
 
     // ---- how the render kernel should visit the column's pixels: entry rectangle by entry rectangle when they
     // cover little of it (the lanes of a 64-pixel chunk are then nearly all covered pixels), otherwise the whole
@@ -730,8 +741,8 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     if (lane == 0 && n_items > 0) item_base = atomicAdd(&g.item_counters[list_shard * PAR_ITEM_COUNTER_STRIDE], n_items);
 
     // ---- B: the shadow walks of this wavefront's share of the occupied bins, one after the other ---------------
-    constexpr int kWalkPart = PAR_COL_WALK / ROLES;
-    const int walk_lo = role * kWalkPart;
+    // The walk area of the record is handed out walk by walk: a team reserves from a counter in LDS (its wavefronts'
+    // walks differ in length: fixed shares would turn away walks that fit), a lone wavefront counts for itself.
     int n_walk = 0;
     bool walk_failed = false;
     if (!overflow && !(a.flags & (1u << 27))) {  // bit 27: ablation (timing experiments only), no walks
@@ -740,7 +751,13 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
             const int sz = sm.nb[i].bz;
             const int n_rec = wave_walk(g, a.count, a.slots, dyn, bx, by, sz, sm.stage, i == 0 ? a.flags : 0u);
             // (a list takes an even number of records: the tile pass reads them in pairs, walk_list_lit)
-            if (n_rec < 0 || n_walk + n_rec + (n_rec & 1) > kWalkPart) {
+            const int need = n_rec + (n_rec & 1);
+            int at = n_walk;
+            if (ROLES > 1 && team && n_rec > 0) {
+                if (lane == 0) at = atomicAdd(&team_sh->walk_used, need);
+                at = wave_bcast(at, 0);
+            }
+            if (n_rec < 0 || at + need > PAR_COL_WALK) {
                 // more occluders on the way than the record holds: the pixels that start here walk for themselves
                 // (lane_shadow_walk in the render kernels), the column keeps its record
                 walk_failed = true;
@@ -749,15 +766,15 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
                     sm.nb[i].wcnt = -1;
                 }
             } else {
-                par_walkrec* dst = g.colrec[ci].walk + walk_lo + n_walk;
+                par_walkrec* dst = g.colrec[ci].walk + at;
                 for (int r = lane; r < n_rec; r += 64) dst[r] = walkrec_of(sm.stage[r]);
                 // a list of odd length repeats its last record behind its end (the result is an OR over the records)
                 if ((n_rec & 1) && lane == 0) dst[n_rec] = walkrec_of(sm.stage[n_rec - 1]);
                 if (lane == 0) {
-                    sm.nb[i].woff = (int16_t)(walk_lo + n_walk);
+                    sm.nb[i].woff = (int16_t)at;
                     sm.nb[i].wcnt = (int16_t)n_rec;
                 }
-                n_walk += n_rec + (n_rec & 1);
+                n_walk += need;
             }
             wave_lds_fence();  // (the next walk overwrites the stage)
         }
@@ -767,11 +784,15 @@ __device__ __forceinline__ void columns_wave(const par_grid_dev& g, const par_re
     // workgroup, and all of them are still here exactly when the column has a walk for each (the same test in all
     // of them): then, and only then, they meet at a barrier.
     bool walks_empty = n_walk == 0 && !walk_failed;
-    if (ROLES > 1 && !overflow && n_nb >= ROLES) {
-        static_assert(ROLES <= 2, "one other wavefront writes the word");
-        if (role != 0 && lane == 0) *others_found = walks_empty ? 0 : 1;
+    if (ROLES > 1 && team) {
+        if (lane == 0) team_sh->found[role] = walks_empty ? 0 : 1;
         __syncthreads();
-        if (role == 0) walks_empty = walks_empty && *others_found == 0;
+        if (role == 0) {
+            int any = 0;
+#pragma unroll
+            for (int r = 0; r < ROLES; r++) any |= team_sh->found[r];
+            walks_empty = any == 0;
+        }
     }
     if (role != 0) {  // the other wavefronts' part of the record: the bins they walked from
         if (ci < g.col_capacity && lane < n_nb && lane % ROLES == role) g.colrec[ci].nb[lane] = sm.nb[lane];
@@ -879,13 +900,15 @@ constexpr int col_waves() { return ROLES == 1 ? 4 : ROLES; }
 // traced).
 template <int ROLES>
 __device__ __forceinline__ void columns_block(const par_grid_dev& g, const par_render_args& a, ColWave* sm,
-                                              int32_t* others_found, int block, int n_cols_bound) {
+                                              ColTeam* team_sh, int block, int n_cols_bound) {
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     __builtin_amdgcn_s_setprio(3);  // latency-bound wavefronts go before the streaming fill's when both want to issue
     if (ROLES == 1) {
-        columns_wave<1>(g, a, sm[wave], others_found, block * col_waves<1>() + wave, 0, n_cols_bound);
+        columns_wave<1>(g, a, sm[wave], team_sh, block * col_waves<1>() + wave, 0, n_cols_bound);
     } else {
-        columns_wave<ROLES>(g, a, sm[wave], others_found, block, wave, n_cols_bound);
+        if (threadIdx.x == 0) team_sh->walk_used = 0;
+        __syncthreads();  // (every wavefront of the workgroup is still here)
+        columns_wave<ROLES>(g, a, sm[wave], team_sh, block, wave, n_cols_bound);
     }
 }
 
@@ -893,8 +916,8 @@ template <int ROLES>
 __global__ __launch_bounds__(col_waves<ROLES>() * 64) void columns_kernel(par_grid_dev g, par_render_args a,
                                                                            int n_cols_bound) {
     __shared__ ColWave sm[col_waves<ROLES>()];
-    __shared__ int32_t others_found;
-    columns_block<ROLES>(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
+    __shared__ ColTeam team_sh;
+    columns_block<ROLES>(g, a, sm, &team_sh, (int)blockIdx.x, n_cols_bound);
     stamp(g, a.flags, 2, 7);
 }
 
@@ -1000,9 +1023,9 @@ __global__ __launch_bounds__(col_waves<ROLES>() * 64) void columns_fill_kernel(p
                                                                                 uint32_t out_rgba, int n_col_blocks,
                                                                                 int n_cols_bound, int2 part) {
     __shared__ ColWave sm[col_waves<ROLES>()];
-    __shared__ int32_t others_found;
+    __shared__ ColTeam team_sh;
     if ((int)blockIdx.x < n_col_blocks) {
-        columns_block<ROLES>(g, a, sm, &others_found, (int)blockIdx.x, n_cols_bound);
+        columns_block<ROLES>(g, a, sm, &team_sh, (int)blockIdx.x, n_cols_bound);
     } else {
         stamp(g, a.flags, 2, 0);
         fill_body(a, out_rgba, nullptr, (int)blockIdx.x - n_col_blocks, (int)gridDim.x - n_col_blocks, part);
@@ -2122,14 +2145,19 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_
                                                                           int n_item_wgs, int n_tile_wgs, int over_parts) {
     __shared__ WaveScratch scratch[PAR_WAVE_NW];
     const int b = (int)blockIdx.x;
+    // (time stamps of debug frames: row 3, a workgroup's start and end, whichever list it serves)
     if (b < n_item_wgs) {
+        stamp(g, DBG ? a.flags : 0u, 3, 0);
         const int w = __builtin_amdgcn_readfirstlane(b * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
         render_items<DBG, true, true, false>(g, a, w, n_item_wgs * PAR_WAVE_NW);
+        stamp(g, DBG ? a.flags : 0u, 3, 7);
         return;
     }
     if (b < n_item_wgs + n_tile_wgs) {
+        stamp(g, DBG ? a.flags : 0u, 3, 0);
         const int w = __builtin_amdgcn_readfirstlane((b - n_item_wgs) * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
         render_items<DBG, true, true, true>(g, a, w, n_tile_wgs * PAR_WAVE_NW);
+        stamp(g, DBG ? a.flags : 0u, 3, 7);
         return;
     }
     const int j = b - n_item_wgs - n_tile_wgs;  // (workgroups of this kind exist only when some column may overflow)
@@ -2324,44 +2352,72 @@ static bool one_wave_per_column(const par_grid_dev& g, const par_render_args& a,
     return !off && (a.flags & PAR_RENDER_PIPELINED) != 0 && std::min(column_bound, cols_in_range) >= 1024;
 }
 
-hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
-                              hipStream_t stream) {
-    const bool pipelined = one_wave_per_column(g, a, column_bound);
+// Wavefronts per column (columns_wave's ROLES): one for a frame among several in flight that fills the chip anyway;
+// otherwise the fewer columns a frame has, the more wavefronts share a column's walks -- a frame with a hundred columns
+// leaves the chip empty, and its columns' walks, one after the other in one or two wavefronts, are most of its
+// column launch (the 480x320 graybox world alone: 13.4 us with two wavefronts per column). PAR_TUNE_COL_ROLES
+// overrides (1, 2, 4 or 8; tools).
+static int column_roles(const par_grid_dev& g, const par_render_args& a, int64_t column_bound) {
+    static const int tuned = [] {
+        const char* e = std::getenv("PAR_TUNE_COL_ROLES");
+        const int v = e ? std::atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 0;
+    }();
+    if (tuned) return tuned;
+    if (one_wave_per_column(g, a, column_bound)) return 1;
+    const int64_t cols_in_range = (int64_t)g.gx * (a.by_hi - a.by_lo + 1);
+    const int64_t cols = std::min(column_bound, cols_in_range);
+    // (measured alone / four in flight, us per frame, 2 -> 4 -> 8 wavefronts per column: graybox 43.4 / 12.3 -> 40.4 /
+    // 11.5 -> 40.2 / 11.5; 512^2 with 64 primitives 26.3 / 7.0 -> 23.8 / 6.9 -> 23.7 / 6.9; 1024^2 with 512: 40.8 /
+    // 14.5 -> 39.2 / 14.6 -> 36.7 / 16.1; 4096^2 with 1 024: 42.5 / 23.5 -> 47.1 / 26.5 -> 59.1 / 36.5)
+    const bool in_flight = (a.flags & PAR_RENDER_PIPELINED) != 0;
+    if (cols <= 256) return 8;
+    if (cols <= 1024) return in_flight ? 4 : 8;
+    return 2;
+}
+
+template <int ROLES>
+static hipError_t launch_columns_as(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                                    const par_fill_plan* fill, hipStream_t stream) {
+    constexpr int waves = col_waves<ROLES>();
     int64_t n_cols;
-    const int64_t blocks = column_blocks(g, a, column_bound, pipelined ? col_waves<1>() : 1, &n_cols);
-    if (blocks <= 0) return hipSuccess;
-    if (pipelined) {
-        hipLaunchKernelGGL(columns_kernel<1>, dim3((unsigned)blocks), dim3(col_waves<1>() * 64), 0, stream, g, a, (int)n_cols);
+    const int64_t n_col_blocks = column_blocks(g, a, column_bound, ROLES == 1 ? waves : 1, &n_cols);
+    if (fill) {
+        // (the same number of fill WAVEFRONTS whatever the workgroup size)
+        const int64_t n_fill = fill_blocks(*fill, 2, waves, 4 * PAR_FILL_RIDE_WGS * 2 / waves);
+        if (n_col_blocks + n_fill <= 0) return hipSuccess;
+        hipLaunchKernelGGL(columns_fill_kernel<ROLES>, dim3((unsigned)(n_col_blocks + n_fill)), dim3(waves * 64), 0, stream,
+                           g, a, fill->out_rgba, (int)n_col_blocks, (int)n_cols, make_int2(fill->cut[2], fill->cut[3]));
     } else {
-        hipLaunchKernelGGL(columns_kernel<2>, dim3((unsigned)blocks), dim3(col_waves<2>() * 64), 0, stream, g, a, (int)n_cols);
+        if (n_col_blocks <= 0) return hipSuccess;
+        hipLaunchKernelGGL(columns_kernel<ROLES>, dim3((unsigned)n_col_blocks), dim3(waves * 64), 0, stream, g, a, (int)n_cols);
     }
-    hipError_t e = hipGetLastError();
+    return hipGetLastError();
+}
+
+static hipError_t launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                                 const par_fill_plan* fill, hipStream_t stream) {
+    hipError_t e;
+    switch (column_roles(g, a, column_bound)) {
+        case 1: e = launch_columns_as<1>(g, a, column_bound, fill, stream); break;
+        case 4: e = launch_columns_as<4>(g, a, column_bound, fill, stream); break;
+        case 8: e = launch_columns_as<8>(g, a, column_bound, fill, stream); break;
+        default: e = launch_columns_as<2>(g, a, column_bound, fill, stream); break;
+    }
     if (e != hipSuccess || !a.trace_bg) return e;
     hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
     return hipGetLastError();
 }
 
+hipError_t par_launch_columns(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
+                              hipStream_t stream) {
+    return launch_columns(g, a, column_bound, nullptr, stream);
+}
+
 // Column records + the last share of the fill in one launch.
 hipError_t par_launch_columns_fill(const par_grid_dev& g, const par_render_args& a, int64_t column_bound,
                                    const par_fill_plan& fill, hipStream_t stream) {
-    const bool pipelined = one_wave_per_column(g, a, column_bound);
-    const int waves = pipelined ? col_waves<1>() : col_waves<2>();
-    int64_t n_cols;
-    const int64_t n_col_blocks = column_blocks(g, a, column_bound, pipelined ? col_waves<1>() : 1, &n_cols);
-    // (the same number of fill WAVEFRONTS whatever the workgroup size)
-    int64_t n_fill = fill_blocks(fill, 2, waves, 4 * PAR_FILL_RIDE_WGS * 2 / waves);
-    if (n_col_blocks + n_fill <= 0) return hipSuccess;
-    if (pipelined) {
-        hipLaunchKernelGGL(columns_fill_kernel<1>, dim3((unsigned)(n_col_blocks + n_fill)), dim3(waves * 64), 0, stream, g,
-                           a, fill.out_rgba, (int)n_col_blocks, (int)n_cols, make_int2(fill.cut[2], fill.cut[3]));
-    } else {
-        hipLaunchKernelGGL(columns_fill_kernel<2>, dim3((unsigned)(n_col_blocks + n_fill)), dim3(waves * 64), 0, stream, g,
-                           a, fill.out_rgba, (int)n_col_blocks, (int)n_cols, make_int2(fill.cut[2], fill.cut[3]));
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || !a.trace_bg) return e;
-    hipLaunchKernelGGL(bgline_kernel, dim3((unsigned)((a.W + 255) / 256)), dim3(256), 0, stream, g, a);
-    return hipGetLastError();
+    return launch_columns(g, a, column_bound, &fill, stream);
 }
 
 hipError_t par_launch_fill(const par_grid_dev& g, const par_render_args& a, hipStream_t stream) {

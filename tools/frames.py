@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Render N frames of one workload (for rocprofv3 --kernel-trace --stats / --pmc runs on the GPU box).
-usage: frames.py [synthetic|floor|graybox|trace_bg] [frames] [extra render flags, e.g. the ablation bits 24-28]"""
+usage: frames.py [synthetic|floor|graybox|small|trace_bg] [frames] [extra render flags, e.g. the ablation bits 24-28]"""
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,6 +21,10 @@ elif what == "floor":
     p = T.default_params(W, H, L)
     a = T.make_aabbs([(i * 20, 0, j * 20, 20, 20, 20) for i in range(W // 20) for j in range(L // 20)])
     l = T.make_light(2560, 2048, 1024)
+elif what == "small":  # BASELINE config 2
+    W = H = L = 512
+    p = T.default_params(W, H, L)
+    a, l = par.scene_synthetic(64, W, H, L, 12345)
 else:
     W, H = 480, 320
     p = T.default_params()
