@@ -446,8 +446,10 @@ par_render_args make_render_args(const par_context* c, int set, int row_begin, i
     }();
     const int64_t grid_cols = (int64_t)c->gx * c->gy;
     const bool dense_frame = dyn_from_device || c->cols_tileable >= std::max<int64_t>(16, grid_cols / 64);
-    a.tile_k = tuned_k >= 0 ? tuned_k
-                            : (!dense_frame ? 0 : (c->total_items >= 65536 ? 5 : (c->total_items >= 16384 ? 3 : (c->total_items >= 8192 ? 2 : 1))));
+    // (what the entities' rectangles add up to, but no more than every column of the grid as a whole tile: the entities
+    // of a crowded small view overlap many times over)
+    const int64_t chunks = std::min(c->total_items, max_items(c));
+    a.tile_k = tuned_k >= 0 ? tuned_k : (!dense_frame ? 0 : (chunks >= 65536 ? 5 : (chunks >= 16384 ? 3 : (chunks >= 8192 ? 2 : 1))));
     a.tile_k_magic = a.tile_k > 0 ? (uint32_t)(65536 / a.tile_k + 1) : 65537u;
     a.dyn = make_dyn(c, c->light);
     a.dyn_ptr = dyn_from_device ? c->d_dyn : nullptr;

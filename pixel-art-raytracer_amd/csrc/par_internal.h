@@ -26,8 +26,14 @@ constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count (bin coordinates a
 // Per-column record built once per frame by columns_kernel and consumed by every wavefront rendering the column.
 constexpr int PAR_COL_NB = 32;          // occupied bins of one column it can describe
 constexpr int PAR_COL_ENT = 64;         // slot records of one column (one per lane of the rendering wavefront)
-constexpr int PAR_BIN_WALK = 64;        // occluder records of one start bin's shadow walk
-constexpr int PAR_COL_WALK = 160;       // occluder records of all walks of one column
+#if !defined(PAR_EXP_BIN_WALK)
+#define PAR_EXP_BIN_WALK 64
+#endif
+#if !defined(PAR_EXP_COL_WALK)
+#define PAR_EXP_COL_WALK 160
+#endif
+constexpr int PAR_BIN_WALK = PAR_EXP_BIN_WALK;  // occluder records of one start bin's shadow walk
+constexpr int PAR_COL_WALK = PAR_EXP_COL_WALK;  // occluder records of all walks of one column
 constexpr int PAR_MIN_BIN = 8, PAR_MAX_BIN = 160;  // supported bin sizes
 constexpr int PAR_TILE_MASKS = 64;      // chunks of a tile visit whose candidate masks the column record carries (one
                                         // lane of the column's wavefront each: bins up to 64 pixels a side)

@@ -1811,8 +1811,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t depth_table(const par_sprite* 
                                              (int)(PAR_SPRITE_TEXELS * sizeof(int32_t)), 0x00020000);
 }
 
-template <bool DBG, bool IDS, bool FULL>
-__device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, int lane) {
+// PIPE: the candidate entries' loads overlap (small frames, bound by their slowest wavefront); without it one entry
+// at a time, the fewest instructions (big dense frames, bound by instruction issue).
+// `depth_lds`: sprite 0's depth table in LDS (tile_depth_to_lds), or nullptr: read it from memory. A depth lookup
+// is then a ds_read (some sixty cycles) instead of a trip through the vector memory path (some five hundred even when
+// the CU's cache has the line), and every candidate entry of a chunk needs one before the next can be compared.
+template <bool DBG, bool IDS, bool FULL, bool PIPE = false>
+__device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const par_render_args& a, uint4 ia, int lane,
+                                                 const int32_t* depth_lds) {
     const uint32_t fl = DBG ? a.flags : 0u;
     const int ci = (int)ia.x;
     const int chunk0 = (int)(ia.y & 0xFFFFu);
@@ -1855,6 +1861,15 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
     const par_strips st = par_strips_of(tw);
     const bool has_ids = IDS && a.sprite_ids != nullptr;
     __amdgpu_buffer_rsrc_t dtab = depth_table(a.sprites, 0);
+    // the depth of sprite 0's texel at byte offset t4 (anything for an offset outside the table: such a lane is outside
+    // the entry's rectangle and its depth is never looked at)
+    auto depth0_at = [&](uint32_t t4) -> int {
+        if (true) {  // (both kernels that render tile items keep the table in LDS)
+            return *reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(depth_lds) +
+                                                     min(t4, (uint32_t)((PAR_SPRITE_TEXELS - 1) * sizeof(int32_t))));
+        }
+        return __builtin_amdgcn_raw_buffer_load_b32(dtab, (int)t4, 0, 0);
+    };
     // the planes, addressed from the visited rectangle's corner with 32-bit pixel offsets
     const size_t corner = (size_t)(rows_lo - a.row_begin) * (size_t)W + (size_t)c0;
 
@@ -1887,11 +1902,10 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
         // alt:289; a lane that is done or has no pixel accepts no entry: nothing lies above INT_MAX
         int closest = lane_of(valid) ? INT_MIN : INT_MAX;
         int w_d = 0, w_pz = 0, w_ent = 0, w_t4 = 0;
-        while (todo) {
-            const int e = __builtin_ctzll(todo);
-            todo = mask_clear(todo, e);
-            u32x8 x = uniform_fetch8(xent, (uint32_t)e * (uint32_t)sizeof(par_xent));
-            uniform_wait(x);
+        // One candidate entry: the bin bookkeeping when its bin differs from the previous candidate's (alt:298-300,
+        // 368-374), the containment test (alt:310-317) and the depth comparison (alt:336-346). `x`: the entry's record,
+        // `d`: its texel depth at this lane's pixel (anything for a lane outside its rectangle).
+        auto candidate = [&](const u32x8& x, int dx4, int srow, uint32_t t4, int d, int sid) {
             const int bzk = (int)x[7];
             if (bzk != cur_bzk) {  // the previous visited bin is complete (alt:368-374), across the bins skipped
                 const lanemask fin = adj1 & hit_bin & ~done;   // adjacent reaches 2
@@ -1905,19 +1919,9 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
                 hit_bin = 0;
                 cur_bzk = bzk;
             }
-            const int dx4 = col4 - (int)x[0];
-            const int srow = (int)x[2] - wj;                                               // alt:324-326
             const uint32_t ex4 = x[1] & 0xFFu, eh = x[1] >> 8;
             // alt:310-317 as two unsigned range tests
             const lanemask in = __ballot((uint32_t)dx4 < ex4) & __ballot((uint32_t)srow < eh);
-            const uint32_t t4 = (uint32_t)(srow * (4 * PAR_SPRITE_W) + dx4);                // alt:330-332, in bytes
-            int sid = 0;
-            if (has_ids) {                                                                 // alt:321-322
-                sid = ld_uniform(a.sprite_ids + (int)x[6]);
-                dtab = depth_table(a.sprites, sid);
-            }
-            // (every lane loads: outside the rectangle t4 is any number; past the table the load returns 0)
-            const int d = __builtin_amdgcn_raw_buffer_load_b32(dtab, (int)t4, 0, 0);
             const int depth = (int)x[4] + min(0, (int)x[3] + wj) - d;                      // alt:336-341
             const lanemask better = __ballot(closest < depth) & in;                        // alt:344-346
             if (lane_of(better)) {
@@ -1928,7 +1932,67 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
                 w_t4 = (int)(t4 + (uint32_t)sid * (uint32_t)(4 * PAR_SPRITE_TEXELS));
             }
             hit_bin |= better;                                                             // alt:365
+        };
+        if (PIPE && !has_ids) {
+            // A frame that is alone on the chip (a small view) is as long as its slowest wavefront, and a chunk of a
+            // crowded column looks at twenty entries, each a scalar load and then a depth lookup that needs it: two
+            // round trips per entry, one after the other. Here they overlap: while entry i is compared, the depth of
+            // entry i + 1 is on its way and the record of entry i + 2 behind it. (Ordinary loads: the compiler has to
+            // see what is in flight across the loop's back edge.)
+            const u32x8* xent8 = reinterpret_cast<const u32x8*>(xent);
+            auto texel_of = [&](const u32x8& x, int& dx4, int& srow, uint32_t& t4) {
+                dx4 = col4 - (int)x[0];
+                srow = (int)x[2] - wj;                                                     // alt:324-326
+                t4 = (uint32_t)(srow * (4 * PAR_SPRITE_W) + dx4);                          // alt:330-332, in bytes
+            };
+            int e1 = todo ? __builtin_ctzll(todo) : 0;
+            lanemask rest = todo ? mask_clear(todo, e1) : 0;  // the candidates behind entry e1
+            int e2 = rest ? __builtin_ctzll(rest) : e1;
+            u32x8 x1 = ld_uniform(xent8 + e1);
+            u32x8 x2 = ld_uniform(xent8 + e2);
+            int dx4_1, srow_1;
+            uint32_t t4_1;
+            texel_of(x1, dx4_1, srow_1, t4_1);
+            int d1 = depth0_at(t4_1);
+            while (todo) {
+                // this round's entry: e1 (record x1, depth d1); next: e2 (record x2 in flight or here)
+                const u32x8 x = x1;
+                const int dx4 = dx4_1, srow = srow_1, d = d1;
+                const uint32_t t4 = t4_1;
+                todo = rest;
+                if (rest) {
+                    rest = mask_clear(rest, e2);
+                    x1 = x2;
+                    e1 = e2;
+                    e2 = rest ? __builtin_ctzll(rest) : e2;
+                    x2 = ld_uniform(xent8 + e2);
+                    texel_of(x1, dx4_1, srow_1, t4_1);
+                    d1 = depth0_at(t4_1);
+                }
+                candidate(x, dx4, srow, t4, d, 0);
+            }
+        } else {
+            while (todo) {
+                const int e = __builtin_ctzll(todo);
+                todo = mask_clear(todo, e);
+                u32x8 x = uniform_fetch8(xent, (uint32_t)e * (uint32_t)sizeof(par_xent));
+                uniform_wait(x);
+                const int dx4 = col4 - (int)x[0];
+                const int srow = (int)x[2] - wj;                                           // alt:324-326
+                const uint32_t t4 = (uint32_t)(srow * (4 * PAR_SPRITE_W) + dx4);            // alt:330-332, in bytes
+                int sid = 0, d;
+                if (has_ids) {                                                             // alt:321-322
+                    sid = ld_uniform(a.sprite_ids + (int)x[6]);
+                    dtab = depth_table(a.sprites, sid);
+                    // (every lane loads: outside the rectangle t4 is any number; past the table the load returns 0)
+                    d = __builtin_amdgcn_raw_buffer_load_b32(dtab, (int)t4, 0, 0);
+                } else {
+                    d = depth0_at(t4);
+                }
+                candidate(x, dx4, srow, t4, d, sid);
+            }
         }
+        stamp(g, fl, 3, 2);  // (debug frames: the primary pass of this workgroup's first wavefront is done)
         // (a pixel was hit exactly when `closest` moved: the comparison alt:344 is strict)
         lanemask hit = __ballot(closest != INT_MIN) & valid;
         if (DBG && (fl & (1u << 26))) hit = 0;  // bit 26: ablation (timing experiments only), no shading
@@ -1961,6 +2025,7 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
         // shadow ray, alt:738-742: the lanes grouped by start bin (bx, by, sz); the bin's walk list (columns kernel)
         // through scalar loads. The start bin's row is the column's own (y + z == world_j, alt:725-726).
         const float fox = (float)(int)(int16_t)col, foy = (float)(int)(int16_t)p_y, foz = (float)(int)(int16_t)p_z;  // alt:720-722
+        stamp(g, fl, 3, 3);  // (... shading up to the shadow test)
         lanemask lit = hit;
         lanemask pending = hit;
         // What a group's inverse directions have in common picks its loop (walk_list_lit's SIGNS). Per lane: the sign
@@ -2014,6 +2079,7 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
             }
             lit &= ~(grp & ~alive);
         }
+        stamp(g, fl, 3, 4);  // (... the shadow test)
         // ---- quantise + store, alt:735, 757-758 ----------------------------------------------------------------
         if (DBG && (fl & PAR_RENDER_COUNT_RAYS) && a.ray_counter) {
             if (lane == 0) atomicAdd(a.ray_counter, (unsigned long long)__popcll(hit));
@@ -2051,8 +2117,9 @@ __device__ __forceinline__ void render_tile_item(const par_grid_dev& g, const pa
 // against 16 KB) -- workgroup v takes shard v mod shards, there the items (v / shards) * NW + its wavefront's
 // number, then on by n_waves / shards. The launch offers one wavefront per item of the host's bound (or per few),
 // so the loop runs once or a few times.
-template <bool DBG, bool IDS, bool FULL, bool TILES>
-__device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves) {
+template <bool DBG, bool IDS, bool FULL, bool TILES, bool PIPE = false>
+__device__ __forceinline__ void render_items(const par_grid_dev& g, const par_render_args& a, int w, int n_waves,
+                                             const int32_t* depth_lds = nullptr) {
     const int lane = (int)threadIdx.x & 63;
     const int wg = w / PAR_WAVE_NW;
     const int shard = wg & (PAR_ITEM_SHARDS - 1);
@@ -2067,7 +2134,7 @@ __device__ __forceinline__ void render_items(const par_grid_dev& g, const par_re
     for (int i = first; i < n;) {
         if (it[0] != PAR_ITEM_NONE) {
             if (TILES) {
-                render_tile_item<DBG, IDS, FULL>(g, a, make_uint4(it[0], it[1], it[2], it[3]), lane);
+                render_tile_item<DBG, IDS, FULL, PIPE>(g, a, make_uint4(it[0], it[1], it[2], it[3]), lane, depth_lds);
             } else {
                 render_item<DBG, IDS, FULL>(g, a, make_uint4(it[0], it[1], it[2], it[3]), make_uint4(it[4], it[5], it[6], it[7]), lane);
             }
@@ -2103,12 +2170,23 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) PAR_RENDER_ATTR void render_items
 // frames only (the host decides, par_render_args::tile_k). In one kernel with the entry passes either path would pay
 // for the other's registers -- the entry passes of a sparse frame are bound by latency and want every wavefront slot,
 // the tile pass is bound by instruction issue and wants its scalars in registers.
+// Sprite 0's depth table into LDS, by the whole workgroup (a barrier: every thread of it must call).
+__device__ __forceinline__ void tile_depth_to_lds(const par_render_args& a, int32_t* depth_lds) {
+    static_assert(PAR_SPRITE_TEXELS % 4 == 0, "copied in 16-byte pieces");
+    const uint4* src = reinterpret_cast<const uint4*>(a.sprites[0].depth);
+    uint4* dst = reinterpret_cast<uint4*>(depth_lds);
+    for (int i = (int)threadIdx.x; i < PAR_SPRITE_TEXELS / 4; i += (int)blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
 template <bool DBG, bool IDS, bool FULL>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_tiles_kernel(par_grid_dev g, par_render_args a) {
+    __shared__ __attribute__((aligned(16))) int32_t depth_lds[PAR_SPRITE_TEXELS];
+    tile_depth_to_lds(a, depth_lds);
     stamp(g, DBG ? a.flags : 0u, 5, 0);
     const unsigned long long core0 = DBG ? __builtin_amdgcn_s_memtime() : 0ull;
     const int w = __builtin_amdgcn_readfirstlane((int)blockIdx.x * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-    render_items<DBG, IDS, FULL, true>(g, a, w, (int)gridDim.x * PAR_WAVE_NW);
+    render_items<DBG, IDS, FULL, true>(g, a, w, (int)gridDim.x * PAR_WAVE_NW, depth_lds);
     stamp(g, DBG ? a.flags : 0u, 5, 7);
     if (DBG && g.stamps && (a.flags & (1u << 29)) && threadIdx.x == 0 && blockIdx.x < PAR_STAMP_WGS) {
         g.stamps[((size_t)5 * PAR_STAMP_WGS + blockIdx.x) * PAR_STAMP_SLOTS + 5] = __builtin_amdgcn_s_memtime() - core0;
@@ -2144,6 +2222,7 @@ template <bool DBG>
 __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_dev g, par_render_args a,
                                                                           int n_item_wgs, int n_tile_wgs, int over_parts) {
     __shared__ WaveScratch scratch[PAR_WAVE_NW];
+    __shared__ __attribute__((aligned(16))) int32_t depth_lds[PAR_SPRITE_TEXELS];
     const int b = (int)blockIdx.x;
     // (time stamps of debug frames: row 3, a workgroup's start and end, whichever list it serves)
     if (b < n_item_wgs) {
@@ -2156,7 +2235,8 @@ __global__ __launch_bounds__(PAR_WAVE_NW * 64) void render_both_kernel(par_grid_
     if (b < n_item_wgs + n_tile_wgs) {
         stamp(g, DBG ? a.flags : 0u, 3, 0);
         const int w = __builtin_amdgcn_readfirstlane((b - n_item_wgs) * PAR_WAVE_NW + ((int)threadIdx.x >> 6));
-        render_items<DBG, true, true, true>(g, a, w, n_tile_wgs * PAR_WAVE_NW);
+        tile_depth_to_lds(a, depth_lds);
+        render_items<DBG, true, true, true, true>(g, a, w, n_tile_wgs * PAR_WAVE_NW, depth_lds);
         stamp(g, DBG ? a.flags : 0u, 3, 7);
         return;
     }
@@ -2533,8 +2613,24 @@ hipError_t par_launch_render_both(const par_grid_dev& g, const par_render_args& 
     if (bound <= 0) return hipSuccess;
     const int over_parts = 8;
     const int64_t over_cols = !may_overflow ? 0 : (bound < 32 ? bound : 32);
-    const int64_t n_item_wgs = item_workgroups(item_bound);
-    const int64_t n_tile_wgs = a.tile_k > 0 ? item_workgroups(tile_item_bound(a, item_bound)) : 0;
+    int64_t n_item_wgs = item_workgroups(item_bound);
+    int64_t n_tile_wgs = a.tile_k > 0 ? item_workgroups(tile_item_bound(a, item_bound)) : 0;
+    if (bound <= 256) {
+        // A frame of a few hundred columns is as long as its slowest wavefront, and a column's items all lie in ONE of
+        // the 64 shards (the column's index picks it): a launch sized by the frame's item count gives the fuller shards
+        // fewer wavefronts than items, and theirs take two or three items one after the other (the 480x320 graybox
+        // world, 94 columns of 25 chunks: 14 us for the launch, of which one chunk's work is 3). So: a wavefront for
+        // every item the fullest shard can hold -- its columns' share, every one of them a whole tile.
+        const int64_t per_col = (((int64_t)a.B * a.B + 63) / 64);
+        const int64_t cols_per_shard = (bound + PAR_ITEM_SHARDS - 1) / PAR_ITEM_SHARDS;
+        // (whole workgroups per shard: render_items deals a list's workgroups to the shards in turn)
+        const int64_t item_wgs_per_shard = (cols_per_shard * per_col + PAR_WAVE_NW - 1) / PAR_WAVE_NW;
+        n_item_wgs = std::max(n_item_wgs, (int64_t)PAR_ITEM_SHARDS * item_wgs_per_shard);
+        if (a.tile_k > 0) {
+            const int64_t tile_wgs_per_shard = (cols_per_shard * ((per_col + a.tile_k - 1) / a.tile_k) + PAR_WAVE_NW - 1) / PAR_WAVE_NW;
+            n_tile_wgs = std::max(n_tile_wgs, (int64_t)PAR_ITEM_SHARDS * tile_wgs_per_shard);
+        }
+    }
     const dim3 grid((unsigned)(n_item_wgs + n_tile_wgs + over_cols * over_parts));
     if (a.flags & PAR_DEBUG_FLAGS) {
         hipLaunchKernelGGL(render_both_kernel<true>, grid, dim3(PAR_WAVE_NW * 64), 0, stream, g, a, (int)n_item_wgs,
