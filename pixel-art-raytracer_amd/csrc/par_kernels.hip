@@ -2552,6 +2552,14 @@ static int64_t item_workgroups(int64_t item_bound) {
     if (per_wave < 1) per_wave = 1;
     if (per_wave > 16) per_wave = 16;
     item_bound = (item_bound + per_wave - 1) / per_wave;
+    // (PAR_TUNE_ITEM_WAVES_PCT, tools: more wavefronts than the bound asks for, in percent: a shard with more items than
+    // its share of the wavefronts makes some of them take two)
+    static const int pct = [] {
+        const char* e = std::getenv("PAR_TUNE_ITEM_WAVES_PCT");
+        const int v = e ? std::atoi(e) : 100;
+        return v < 50 ? 50 : (v > 400 ? 400 : v);
+    }();
+    item_bound = item_bound * pct / 100;
     int64_t waves = (item_bound + unit - 1) / unit * unit;
     if (waves < unit) waves = unit;
     if (waves > (int64_t)1 << 24) waves = (int64_t)1 << 24;  // (the wavefronts then loop over their shard)
