@@ -447,20 +447,25 @@ __device__ __forceinline__ void normalize_l1_and_inverse(float x, float y, float
 __device__ __forceinline__ void walk_chain_block(float& vx, float& vy, float& vz, float sx, float sy, float sz,
                                                  uint64_t lanes) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // (x and y in one packed instruction: v_pk_add_f32 is two IEEE single-precision additions, each rounded as
+    // v_add_f32 rounds it -- two vector instructions per step instead of three)
     uint64_t saved;
+    v2f vxy = {vx, vy};
+    const v2f sxy = {sx, sy};
     asm volatile(
         "s_mov_b64 %[sv], exec\n"
         "s_mov_b64 exec, %[m0]\n"
         ".rept 16\n"
-        "v_add_f32 %[x], %[x], %[sx]\n"
-        "v_add_f32 %[y], %[y], %[sy]\n"
+        "v_pk_add_f32 %[xy], %[xy], %[sxy]\n"
         "v_add_f32 %[z], %[z], %[sz]\n"
         "s_lshl_b64 exec, exec, 1\n"
         ".endr\n"
         "s_mov_b64 exec, %[sv]\n"
-        : [x] "+v"(vx), [y] "+v"(vy), [z] "+v"(vz), [sv] "=&s"(saved)
-        : [sx] "v"(sx), [sy] "v"(sy), [sz] "v"(sz), [m0] "s"(lanes)
+        : [xy] "+v"(vxy), [z] "+v"(vz), [sv] "=&s"(saved)
+        : [sxy] "v"(sxy), [sz] "v"(sz), [m0] "s"(lanes)
         : "scc");
+    vx = vxy.x;
+    vy = vxy.y;
 #else
     (void)vx; (void)vy; (void)vz; (void)sx; (void)sy; (void)sz; (void)lanes;
 #endif
