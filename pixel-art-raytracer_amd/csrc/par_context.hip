@@ -45,6 +45,10 @@ struct par_context {
     // every moved entity on the host, every frame); the next blocking call brings it up to date (refresh_exact).
     int64_t bound_pairs = 0, bound_cols = 0, bound_items = 0;
     bool exact_stale = false;
+    // The per-column histograms alone lag behind the footprints (par_graph_stage keeps footprints and totals exact --
+    // it has to refuse a frame the captured launches cannot hold -- but not the histograms, which cost a moving scene
+    // more host time per frame than everything else the stage does; a captured graph does not read them).
+    bool hist_stale = false;
     std::vector<int32_t> h_colpairs;  // (entity, bin) pairs per screen column (>= its occupied bins, >= its entries)
     int64_t cols_over = 0;            // columns with more pairs than a column record is sure to hold
     // 64-pixel chunks of the entities' sprite rectangles per screen column (what the column kernel adds up, over the
@@ -266,7 +270,7 @@ void commit_update(par_context* c, const par_aabb* aabbs, int first, int n, cons
 // The exact bookkeeping (footprints, totals, per-column histograms) from the host's copy of the AABBs, after
 // asynchronous updates left it stale.
 void refresh_exact(par_context* c) {
-    if (!c->exact_stale) return;
+    if (!c->exact_stale && !c->hist_stale) return;
     c->h_colpairs.assign((size_t)c->gx * c->gy, 0);
     c->h_colchunks.assign((size_t)c->gx * c->gy, 0);
     c->cols_over = 0;
@@ -281,6 +285,22 @@ void refresh_exact(par_context* c) {
         c->total_items += f.items;
     }
     c->exact_stale = false;
+    c->hist_stale = false;
+}
+
+// commit_update without the per-column histograms (they go stale: hist_stale).
+void commit_update_totals(par_context* c, const par_aabb* aabbs, int first, int n, const par_update_plan& plan) {
+    par_bound bt;
+    bounds_after(c, aabbs, first, n, &bt);
+    c->bound_pairs = bt.pairs; c->bound_cols = bt.cols; c->bound_items = bt.items;
+    for (int i = 0; i < n; i++) {
+        c->h_fp[(size_t)(first + i)] = plan.fp[(size_t)i];
+        c->h_aabbs[(size_t)(first + i)] = aabbs[i];
+    }
+    c->total_pairs = plan.pairs;
+    c->total_cols = plan.cols;
+    c->total_items = plan.items;
+    c->hist_stale = true;
 }
 
 bool extent_ok(const par_aabb& a) {
@@ -524,7 +544,7 @@ int enqueue_frame(par_context* ctx, hipStream_t stream, int set, int row_begin, 
     // The overflow list is empty for sure while no column has more pairs than a record holds (a captured graph also
     // serves later frames, whose columns nobody knows yet): then the frame has no launch for it, and the column
     // kernel flags the frame should a column overflow all the same.
-    const bool may_overflow = graph_mode || ctx->cols_over > 0 || ctx->exact_stale || r.dense ||
+    const bool may_overflow = graph_mode || ctx->cols_over > 0 || ctx->exact_stale || ctx->hist_stale || r.dense ||
                               (ev && !(flags & PAR_RENDER_TIMED_AS_LAUNCHED));
     r.overflow_launched = may_overflow ? 1 : 0;
     if ((flags & PAR_RENDER_COUNT_RAYS) && !graph_mode) {
@@ -1143,13 +1163,14 @@ static int par_graph_stage_impl(par_context* ctx, const par_aabb* aabbs, int fir
     for (int i = 0; i < n; i++) {
         if (!extent_ok(aabbs[i])) return fail(ctx, PAR_ERR_EXTENT, "extent needs 0<=ex<=20, ey,ez>=0, ey+ez<=40");
     }
-    refresh_exact(ctx);
+    if (ctx->exact_stale) refresh_exact(ctx);  // (the footprints and totals; the histograms may stay behind)
     par_update_plan plan;
     plan_update(ctx, aabbs, first, n, &plan);
+
     if (plan.pairs > ctx->graph_pair_bound || plan.pairs > ctx->grid.capacity) {
         return fail(ctx, PAR_ERR_UNSUPPORTED, "staged frame exceeds what the captured graph was sized for; capture again");
     }
-    commit_update(ctx, aabbs, first, n, plan);
+    commit_update_totals(ctx, aabbs, first, n, plan);
     mark_staged(ctx, first, n);  // (the staging areas are brought up to date by par_graph_launch)
     if (light) ctx->light = *light;
     return PAR_OK;
@@ -1158,7 +1179,7 @@ static int par_graph_stage_impl(par_context* ctx, const par_aabb* aabbs, int fir
 static int par_graph_launch_impl(par_context* ctx, void* stream) {
     if (!ctx || !ctx->graph_exec[0]) return fail(ctx, PAR_ERR_NOT_READY, "no captured graph");
     // (the scene may also have been changed by par_update_aabbs[_async]: same limit as par_graph_stage)
-    refresh_exact(ctx);
+    if (ctx->exact_stale) refresh_exact(ctx);
     if (ctx->total_pairs > ctx->graph_pair_bound) {
         return fail(ctx, PAR_ERR_UNSUPPORTED, "the scene exceeds what the captured graph was sized for; capture again");
     }
