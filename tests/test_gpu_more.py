@@ -41,6 +41,18 @@ def test_graph_replay_with_moving_primitives(par, oracle, sprite, T):
             exp = oracle.render(params, aabbs, sprite, light, planes=("fb", "palidx"))
             assert np.array_equal(fb.cpu().numpy(), exp["fb"].view(np.uint8)), f"frame {f}"
             assert np.array_equal(pal.cpu().numpy(), exp["palidx"]), f"frame {f}"
+        # staging keeps the host's footprints and totals exact but lets the per-column histograms lag: a frame
+        # rendered the ordinary way right after must come out the same (sized for an overflow list it cannot rule out),
+        # and so must one rendered after a blocking update has brought the histograms up to date
+        got = r.render(("fb", "palidx"))
+        assert np.array_equal(got["fb"].view(np.uint8), exp["fb"].view(np.uint8)), "blocking render after staging"
+        assert np.array_equal(got["palidx"], exp["palidx"]), "blocking render after staging"
+        aabbs["px"] += vel[:, 0].astype(np.int16)
+        r.update_aabbs(aabbs, 0)
+        exp = oracle.render(params, aabbs, sprite, light, planes=("fb", "palidx"))
+        got = r.render(("fb", "palidx"))
+        assert np.array_equal(got["fb"].view(np.uint8), exp["fb"].view(np.uint8)), "after a blocking update"
+        assert np.array_equal(got["palidx"], exp["palidx"]), "after a blocking update"
 
 
 def test_update_aabbs_between_frames(par, oracle, sprite, T):
