@@ -292,6 +292,47 @@ print("generic ok")
     assert p.returncode == 0 and "generic ok" in p.stdout, p.stderr[-3000:]
 
 
+def test_column_teams_of_every_size():
+    """The column launch's workgroups are teams of 1, 2, 4 or 8 wavefronts per column, chosen by the frame's size and
+    by whether it is one of several in flight; PAR_TUNE_COL_ROLES forces one size (read once per process: a fresh
+    process per size). Every size on a crowded small view (the graybox world: walls of many occupied bins per column,
+    lists that wrap), a mid-size random view, long walks to a far light and columns at the edge of a record -- every
+    plane against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import importlib, sys
+sys.path.insert(0, %r)
+import numpy as np
+par = importlib.import_module("pixel-art-raytracer_amd"); T = par.types
+from oracle.oracle import Oracle
+o = Oracle(); sprite = par.tile_floor()
+ALL = ("fb", "gbuf", "palidx", "brightness", "lit")
+scenes = [(T.default_params(), par.scene_graybox(), T.make_light(480, 160, 80))]
+for (w, h, l, n, seed, b) in [(640, 400, 400, 300, 3, 40), (1024, 768, 512, 400, 9, 40), (320, 200, 1600, 250, 4, 8)]:
+    a, li = par.scene_synthetic(n, w, h, l, seed)
+    scenes.append((T.default_params(w, h, l, b), a, li))
+# one screen column crowded with boxes along z (many occupied bins, many walks, lists near the record's limits)
+rows = [(200 + (i %% 2) * 10, 40, 10 + 36 * i, 20, 20, 20) for i in range(30)] + [(100, 100, 100, 20, 20, 20)]
+scenes.append((T.default_params(480, 320, 1200), T.make_aabbs(rows), T.make_light(470, 300, 1100)))
+for params, aabbs, light in scenes:
+    exp = o.render(params, aabbs, sprite, light, nthreads=8)
+    with par.Renderer(params) as r:
+        r.set_scene(aabbs, sprite, light)
+        for planes in (("fb", "palidx"), ALL):
+            out = r.render(planes)
+            for k in planes:
+                assert out[k].tobytes() == exp[k].tobytes(), (params.width, params.height, k)
+print("teams ok")
+''' % root
+    for roles in ("1", "2", "4", "8"):
+        env = dict(os.environ, PAR_TUNE_COL_ROLES=roles)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0 and "teams ok" in p.stdout, (roles, p.stderr[-3000:])
+
+
 def test_every_ray_traced_mode(par, oracle, sprite, T):
     """PAR_RENDER_TRACE_BACKGROUND without a lit plane, and the lit plane at full size: background rays included,
     the lit mask equals the oracle's (trace_hash_for_light for every pixel, alt:703-742)."""
