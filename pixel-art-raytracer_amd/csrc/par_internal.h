@@ -26,6 +26,8 @@ constexpr int PAR_MAX_GRID_DIM = 1024;  // per-axis bin count (bin coordinates a
 // Per-column record built once per frame by columns_kernel and consumed by every wavefront rendering the column.
 constexpr int PAR_COL_NB = 32;          // occupied bins of one column it can describe
 constexpr int PAR_COL_ENT = 64;         // slot records of one column (one per lane of the rendering wavefront)
+// (experiments, tools/debug/variants.sh: -DPAR_EXP_BIN_WALK=... -DPAR_EXP_COL_WALK=... ; larger records bought nothing
+// on the graybox world and cost the big views)
 #if !defined(PAR_EXP_BIN_WALK)
 #define PAR_EXP_BIN_WALK 64
 #endif

@@ -9,7 +9,8 @@
 //   columns_fill_kernel     columns_wave: per occupied column its compact slot list and the bin walks of
 //                           trace_hash_for_light (alt:399-500; they depend on the start bin only) -> one record,
 //                           and the column's work items: one per 64-pixel chunk of an entry-by-entry visit, or one
-//                           per tile_k chunks of a whole-tile visit (dense frames)
+//                           per tile_k chunks of a whole-tile visit (dense frames). A column's walks are shared by
+//                           a team of 1, 2, 4 or 8 wavefronts (the fewer columns a frame has, the more)
 //   render_items_kernel     trace_hash_for_pixel alt:271-397, the shading loop alt:702-760, AABB::intersect
 //                           alt:40-83, Vector::normalize spr:28-35, Color::operator* spr:8-16 -- one wavefront
 //                           per entry-pass work item, from the column records, no workgroup cooperation
@@ -17,7 +18,8 @@
 //                           records, lane masks in scalar registers); launched for dense frames only
 //   render_overflow_kernel  the columns that overflow a record: straight from the hash, walks in-kernel; launched
 //                           only when the host cannot rule an overflow out (PAR_FORCE_GENERIC=1: every column)
-//   (render_both_kernel     the render kernels in one launch for small frames, which are bound by their launches)
+//   (render_both_kernel     the render kernels in one launch for small frames, which are bound by their launches and
+//                           by their slowest wavefront: a wavefront for every item the fullest shard can hold)
 // The background fill (alt:281 -> alt:735, pure streaming) has no launch of its own: the first two launches each
 // carry a share of it (extra workgroups running fill_body), sized so that it rides along in their shadow.
 // When other planes are asked for (G-buffer, brightness, lit) or the view is not 8-pixel aligned, the hash
