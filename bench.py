@@ -117,6 +117,9 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
     import torch
     w, h = params.width, params.height
     pipe = pipeline.FramePipeline(params, aabbs, sprite, light, depth=depth, device=device, planes=("fb", "palidx"))
+    # (a small frame is bound by the host's launches when ONE thread submits for all slots: one thread per slot there,
+    # as a C++ host would -- host/par_pipeline.cpp --threads)
+    threaded = w * h <= (1 << 21)
     try:
         pipe.submit_many(0, 4 * depth)
         pipe.synchronize()
@@ -124,7 +127,7 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
         for _ in range(5):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            pipe.submit_many(0, steps)
+            pipe.submit_many(0, steps, threads=threaded)
             pipe.synchronize()
             ms.append((time.perf_counter() - t0) / steps * 1e3)
         per = statistics.median(ms)
@@ -167,6 +170,7 @@ def side_scene(par, pipeline, T, name, params, aabbs, light, sprite, device, dep
         covered = int((full["palidx"] != T.PALIDX_BACKGROUND).sum())
         return {
             "workload": name, "ms_per_frame": round(per, 5), "frames_in_flight": depth,
+            "submitting_threads": depth if threaded else 1,
             "mrays_per_s": round(2.0 * w * h / per / 1e3, 1),
             "hbm_frac": round(5.0 * w * h / (per * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
             "one_frame_at_a_time_ms": round(alone, 5),

@@ -91,9 +91,15 @@ class FramePipeline:
     def slot(self, i):
         return self.slots[i % len(self.slots)]
 
-    def submit_many(self, first, n, flags=0):
+    def submit_many(self, first, n, flags=0, threads=False):
         """Enqueue frames first .. first + n - 1 round-robin over the slots with ONE call into the library
-        (par_render_device_slots): the render loop of the swap chain runs in C, not in the interpreter."""
+        (par_render_device_slots): the render loop of the swap chain runs in C, not in the interpreter.
+        `threads`: one submitting thread per slot instead (each calls the library for its own slot's frames; a slot's
+        context is only ever touched by its own thread, and ctypes releases the interpreter lock for the call): small
+        frames are bound by the host's launches -- four launches of 3-4 us per graybox frame against 10 us of device
+        time -- and how fast one host thread is differs from box to box (host/par_pipeline.cpp --threads does the same)."""
+        if threads and len(self.slots) > 1 and n >= 4 * len(self.slots):
+            return self._submit_threaded(first, n, flags)
         if getattr(self, "_slot_args", None) is None:
             k = len(self.slots)
             ctxs = (C.c_void_p * k)(*[s.renderer._ctx for s in self.slots])
@@ -106,6 +112,28 @@ class FramePipeline:
         rc = lib().par_render_device_slots(ctxs, streams, outs, len(self.slots), r0, r1, first, n, flags)
         if rc != 0:
             raise RuntimeError(f"par_render_device_slots failed with status {rc}")
+
+    def _submit_threaded(self, first, n, flags):
+        from concurrent.futures import ThreadPoolExecutor
+        k = len(self.slots)
+        if getattr(self, "_pool", None) is None:
+            self._pool = ThreadPoolExecutor(k)
+            self._one = []
+            for s in self.slots:
+                self._one.append(((C.c_void_p * 1)(s.renderer._ctx), (C.c_void_p * 1)(s.stream.cuda_stream),
+                                  (Outputs * 1)(Outputs(*[s.ptrs.get(p) for p in ("fb", "gbuf", "palidx", "brightness", "lit")]))))
+        r0, r1 = self.slots[0].rows
+        device = self.slots[0].stream.device
+
+        def run(j, count):
+            torch.cuda.set_device(device)
+            ctxs, streams, outs = self._one[j]
+            return lib().par_render_device_slots(ctxs, streams, outs, 1, r0, r1, 0, count, flags | RENDER_PIPELINED)
+
+        counts = [len(range(first + ((j - first) % k), first + n, k)) for j in range(k)]  # frames f with f % k == j
+        for rc in self._pool.map(run, range(k), counts):
+            if rc != 0:
+                raise RuntimeError(f"par_render_device_slots failed with status {rc}")
 
     def kernel_spans_us(self):
         """Per kernel of the frame, the mean span (first workgroup start to last workgroup end, microseconds) over the
@@ -147,5 +175,8 @@ class FramePipeline:
 
     def close(self):
         self.synchronize()
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown()
+            self._pool = None
         for s in self.slots:
             s.renderer.close()
