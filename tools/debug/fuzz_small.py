@@ -13,17 +13,21 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time(); n_cases = 0; n_skipped = 0; n_px = 0
 while time.time() - t0 < secs:
     b = int(rng.choice([8, 16, 20, 24, 32, 40, 40, 40, 64, 100, 160]))
-    w = int(rng.integers(3, 120)) * 8 if rng.random() < 0.7 else int(rng.integers(20, 900))
-    h, l = int(rng.integers(30, 700)), int(rng.integers(30, 900))
+    if os.environ.get("FUZZ_BIG"):  # mid-size views: the big frames' launch shapes, tile items of several chunks
+        w, h, l = int(rng.integers(64, 256)) * 8, int(rng.integers(400, 2048)), int(rng.integers(200, 2048))
+        b = int(rng.choice([20, 32, 40, 40, 40, 64]))
+    else:
+        w = int(rng.integers(3, 120)) * 8 if rng.random() < 0.7 else int(rng.integers(20, 900))
+        h, l = int(rng.integers(30, 700)), int(rng.integers(30, 900))
     kind = int(rng.integers(0, 4))
     if kind == 0:    # sparse random boxes
-        n = int(rng.integers(1, 400)); aabbs, light = par.scene_synthetic(n, w, h, l, int(rng.integers(1, 1 << 30)))
+        n = int(rng.integers(1, 400 if not os.environ.get("FUZZ_BIG") else 3000)); aabbs, light = par.scene_synthetic(n, w, h, l, int(rng.integers(1, 1 << 30)))
     elif kind == 1:  # crowded: boxes folded into a corner
         n = int(rng.integers(50, 600)); aabbs, light = par.scene_synthetic(n, w, h, l, int(rng.integers(1, 1 << 30)))
         aabbs["px"] = (aabbs["px"] % max(3 * b, 60)).astype(aabbs["px"].dtype)
         aabbs["pz"] = (aabbs["pz"] % max(4 * b, 80)).astype(aabbs["pz"].dtype)
     elif kind == 2:  # a floor with boxes of every extent on it
-        rows = [(i * 20, 0, j * 20, 20, 20, 20) for i in range((w + 19) // 20) for j in range(max(l // 20, 1))][:6000]
+        rows = [(i * 20, 0, j * 20, 20, 20, 20) for i in range((w + 19) // 20) for j in range(max(l // 20, 1))][:6000 if not os.environ.get("FUZZ_BIG") else 12000]
         rows += [(int(rng.integers(0, max(w - 20, 1))), int(rng.integers(0, 150)), int(rng.integers(0, max(l - 20, 1))),
                   int(rng.integers(1, 21)), int(rng.integers(1, 21)), int(rng.integers(1, 21))) for _ in range(int(rng.integers(0, 200)))]
         aabbs = T.make_aabbs(rows); light = T.make_light(int(rng.integers(0, w)), int(rng.integers(20, h)), int(rng.integers(0, l)))
